@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the CTC loss+gradient hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU.  One "step" = one loss+gradient call (loss[B] and
+grad[B,T,V] w.r.t. logits) over one batch of synthetic logits that already sits in HBM.
+Workload = BASELINE.json configs[1]: classic_ctc_loss B=256 T=1000 U=128 V=256 fp32 per GPU
+(`--kind simplified` gives configs[2]; `--ragged` the ragged-length variant; `--hessian` configs[4]).
+The batch axis shards across ranks with no data-path collective (weak scaling: 256 utterances per GPU);
+the only collective is the all-reduce of the scalar sum of losses (RCCL), issued every step.
+
+Rank 0 prints ONE JSON line with the fields the driver reads plus
+  "roofline":     HBM roofline of the loss+grad pipeline (algorithmic bytes 2*T*V*4 per utterance)
+  "cpu_baseline": the oracle (NumPy restatement of the reference, oracle/ctc_oracle.py) timed on this
+                  box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def make_inputs(B, T, U, V, seed, ragged, device):
+    """BASELINE.md 'Inputs (configs 2/3)': numpy default_rng(seed); logits N(0,1), labels uniform non-blank,
+    full lengths (ragged variant: logit_length ~ U{T/2..T-1}, label_length ~ U{U/2..U})."""
+    rng = np.random.default_rng(seed)
+    logits = rng.standard_normal((B, T, V), dtype=np.float32)
+    labels = rng.integers(1, V, (B, U), dtype=np.int32)
+    if ragged:
+        logit_length = rng.integers(T // 2, T, B, dtype=np.int32)
+        label_length = rng.integers(U // 2, U + 1, B, dtype=np.int32)
+    else:
+        logit_length = np.full(B, T, dtype=np.int32)
+        label_length = np.full(B, U, dtype=np.int32)
+    host = dict(logits=logits, labels=labels, label_length=label_length, logit_length=logit_length)
+    dev = {k: torch.from_numpy(v).to(device) for k, v in host.items()}
+    return host, dev
+
+
+def cpu_baseline(kind, host, budget_s=20.0):
+    """Times the oracle (fp32 arithmetic, like the reference) on the first few utterances of the workload."""
+    from oracle import ctc_oracle as O
+    n = 2
+    t0 = time.perf_counter()
+    d = O.ctc_loss(kind, host["labels"][:n], host["logits"][:n], host["label_length"][:n], host["logit_length"][:n], 0,
+                   dtype=np.float32)
+    _ = d.loss
+    _ = O.logits_gradient(d, host["logits"][:n])
+    dt = time.perf_counter() - t0
+    # one more, larger sample if the first one was quick
+    n2 = int(max(n, min(host["logits"].shape[0], n * budget_s / max(dt, 1e-3) / 2)))
+    if n2 > n:
+        t0 = time.perf_counter()
+        d = O.ctc_loss(kind, host["labels"][:n2], host["logits"][:n2], host["label_length"][:n2],
+                       host["logit_length"][:n2], 0, dtype=np.float32)
+        _ = d.loss
+        _ = O.logits_gradient(d, host["logits"][:n2])
+        dt = time.perf_counter() - t0
+        n = n2
+    return dict(value=n / dt, unit="utterances/s", cores=1, kind="port",
+                sample=f"oracle/ctc_oracle.py (NumPy fp32, 1 thread) loss+grad on the first {n} utterances of the workload, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--kind", default="classic", choices=["classic", "simplified"])
+    ap.add_argument("--B", type=int, default=256)
+    ap.add_argument("--T", type=int, default=1000)
+    ap.add_argument("--U", type=int, default=128)
+    ap.add_argument("--V", type=int, default=256)
+    ap.add_argument("--ragged", action="store_true")
+    ap.add_argument("--hessian", action="store_true", help="time the dense Hessian at B=32 T=200 U=32 V=64 (configs[4])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from tf_seq2seq_losses_amd import _lib, ops
+
+    if args.hessian:
+        args.B, args.T, args.U, args.V = 32, 200, 32, 64
+    B, T, U, V = args.B, args.T, args.U, args.V
+    kind = ops.KINDS[args.kind]
+    host, dev = make_inputs(B, T, U, V, seed=rank, ragged=args.ragged, device=device)
+    prep = ops.Prepared(dev["labels"], dev["logits"], dev["label_length"], dev["logit_length"], 0, U=U)
+    total = torch.zeros((), dtype=torch.float32, device=device)
+
+    if args.hessian:
+        ws = torch.empty(_lib.workspace_bytes(_lib.WS_HESSIAN, kind, B, T, V, U), dtype=torch.uint8, device=device)
+        loss = torch.empty(B, dtype=torch.float32, device=device)
+        hess = torch.empty((B, T, V, T, V), dtype=torch.float32, device=device)
+        lib = _lib.load()
+
+        def step():
+            rc = lib.ctc_amd_hessian(*prep.common(kind, _lib.WRT_LOGITS), loss.data_ptr(), None, hess.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "ctc_amd_hessian")
+            return loss
+        alg_bytes = B * ((T * V) ** 2 * 4 + T * V * 4)
+    else:
+        ws = torch.empty(_lib.workspace_bytes(_lib.WS_LOSS_GRAD, kind, B, T, V, U), dtype=torch.uint8, device=device)
+
+        def step():
+            loss, grad = ops.loss_grad(kind, _lib.WRT_LOGITS, prep, want_grad=True, workspace=ws)
+            return loss
+        alg_bytes = B * 2 * T * V * 4
+
+    def full_step():
+        loss = step()
+        s = loss.sum()
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(s)  # the one collective of the path: scalar sum of the losses over RCCL/xGMI
+        total.copy_(s)
+
+    for _ in range(args.warmup):
+        full_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        full_step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    tmax = torch.tensor([wall], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = wall * 1e3 / args.steps
+        value = B * world * args.steps / wall
+        dev_ms_per_step = dev_ms / args.steps
+        achieved = alg_bytes / (dev_ms_per_step * 1e-3) / 1e9
+        out = {
+            "metric": "utterances/sec (loss+grad) at B=256 T=1000 U=128 V=256; HBM roofline %" if not args.hessian
+            else "utterances/sec (dense Hessian) at B=32 T=200 U=32 V=64",
+            "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.kind}_ctc_loss {'hessian' if args.hessian else 'loss+grad'} B={B} T={T} U={U} V={V} fp32 per GPU"
+                                   + (" ragged" if args.ragged else " full-length"),
+                       "global_batch": B * world, "parallelism": f"batch-sharded x{world}, all-reduce of sum(loss)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "emit_kernel + scan_kernel + grad_kernel (one loss+grad call)",
+                         "algorithmic_bytes_per_call": alg_bytes, "device_ms_per_call": dev_ms_per_step},
+        }
+        if not args.no_cpu_baseline and not args.hessian:
+            out["cpu_baseline"] = cpu_baseline(args.kind, host)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+/*
+ * ctc_amd.h -- C ABI of the MI355X-native CTC loss (loss, analytic gradient, analytic Hessian).
+ *
+ * This is the drop-in boundary for the hot path of alexeytochin/tf_seq2seq_losses.  The reference has
+ * no FFI of its own (it is pure Python on TensorFlow); the entry points below are what a binding for
+ * its two public functions and its loss-data properties would call.  Each one cites the reference
+ * interface it replaces (paths relative to the reference repo, v0.3.0).
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (HIP, gfx950) unless a parameter says "host".
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Every entry point is
+ *     asynchronous on that stream, performs no allocation, no host<->device copy and no device
+ *     synchronisation, and is therefore capturable into a hipGraph.
+ *   - The caller owns every buffer, including the workspace (size from ctc_amd_workspace_bytes).
+ *     Outputs are fully overwritten.  The library keeps no global state besides a thread-local
+ *     error string; calls are re-entrant for distinct (stream, workspace) pairs.
+ *   - Layouts are dense row-major: logits[B][T][V] float32, labels[B][label_stride] int32,
+ *     label_length[B], logit_length[B] int32, loss[B], grad[B][T][V], hess[B][T][V][T][V] float32.
+ *   - `U` is a static upper bound on label_length (the reference uses the dynamic max(label_length),
+ *     base_loss.py:482-486; any U >= max(label_length) gives identical loss/gradient/Hessian because
+ *     the extra lattice states stay at log 0).  A sample with label_length[b] > U gets loss = +inf.
+ *   - Return value: 0 on success, negative CTC_AMD_E* code otherwise; ctc_amd_last_error() has text.
+ *     Not errors (reference semantics, classic_ctc_loss.py:50-52, base_loss.py:240-245,283-288):
+ *     infeasible alignment => loss = +inf, gradient = 0, Hessian = 0; B == 0; T == 0.
+ */
+#ifndef CTC_AMD_H
+#define CTC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTC_AMD_ABI_VERSION 1
+
+/* lattice variant */
+#define CTC_AMD_CLASSIC 0    /* classic_ctc_loss.py:33-70   (collapse repeats, then drop blanks)   */
+#define CTC_AMD_SIMPLIFIED 1 /* simplified_ctc_loss.py:32-67 (drop blanks only)                     */
+
+/* what the float input is / what the derivatives are taken with respect to */
+#define CTC_AMD_WRT_LOGITS 0   /* input = logits; log_softmax fused (base_loss.py:59, tools.py:27-40);
+                                  derivatives w.r.t. logits (what tf.GradientTape returns to the user) */
+#define CTC_AMD_WRT_LOGPROBS 1 /* input = log-probabilities treated as independent variables
+                                  (base_loss.py:71-99); derivatives w.r.t. them (loss_data.gradient /
+                                  loss_data.hessian, base_loss.py:186-268)                            */
+
+/* error codes */
+#define CTC_AMD_OK 0
+#define CTC_AMD_EINVAL (-1)     /* bad argument (null pointer, negative size, unsupported shape)      */
+#define CTC_AMD_EWORKSPACE (-2) /* workspace too small                                                */
+#define CTC_AMD_EHIP (-3)       /* HIP runtime error (launch failure)                                 */
+
+/* selector for ctc_amd_workspace_bytes */
+#define CTC_AMD_WS_LOSS_GRAD 0
+#define CTC_AMD_WS_ALPHA_BETA 1
+#define CTC_AMD_WS_HESSIAN 2
+
+/* ABI version of the loaded library (== CTC_AMD_ABI_VERSION of the header it was built from). */
+int ctc_amd_abi_version(void);
+
+/* Thread-local text of the last error returned on this thread ("" if none). */
+const char *ctc_amd_last_error(void);
+
+/* Bytes of device workspace the call selected by `what` needs for these shapes. */
+int ctc_amd_workspace_bytes(int what, int kind, int B, int T, int V, int U, size_t *out_bytes /*host*/);
+
+/*
+ * Loss and (optionally) its gradient.
+ * Replaces: classic_ctc_loss / simplified_ctc_loss forward (classic_ctc_loss.py:33-70,
+ * simplified_ctc_loss.py:32-67 -> base_loss.py:38-99 -> loss_data.loss) and the first-order backward
+ * forward_fn.backprop = d_loss[:,None,None] * gradient (base_loss.py:140-155, 262-298) composed with TF's
+ * autodiff of log_softmax (tools.py:37-39) when wrt == CTC_AMD_WRT_LOGITS.
+ *   grad   may be NULL (loss only).
+ *   d_loss may be NULL (== ones); otherwise [B] upstream gradient that scales each sample's gradient.
+ */
+int ctc_amd_loss_grad(int kind, int wrt,
+                      const float *logits, const int32_t *labels, int label_stride,
+                      const int32_t *label_length, const int32_t *logit_length, int blank_index,
+                      int B, int T, int V, int U,
+                      float *loss, float *grad, const float *d_loss,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Forward/backward lattice variables in the reference's own layout and units (natural log, -inf for
+ * impossible states): classic alpha/beta[B][T+1][U+1][2] (s=0 closed, s=1 open), simplified [B][T+1][U+1].
+ * Replaces: ClassicCtcLossData.alpha/.beta (classic_ctc_loss.py:310-462), SimplifiedCtcLossData.alpha/.beta
+ * (simplified_ctc_loss.py:291-438).  Parity/debug entry point; not on the fast path.
+ * Here U must equal max(label_length) for the shapes to match the reference's.
+ */
+int ctc_amd_alpha_beta(int kind, int wrt,
+                       const float *logits, const int32_t *labels, int label_stride,
+                       const int32_t *label_length, const int32_t *logit_length, int blank_index,
+                       int B, int T, int V, int U,
+                       float *loss, float *alpha, float *beta,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Dense Hessian hess[B][T][V][T][V] (the O(l^4) path), plus loss and gradient (grad may be NULL).
+ * Replaces: loss_data.hessian (base_loss.py:186-260) for wrt == CTC_AMD_WRT_LOGPROBS, and
+ * tape.batch_jacobian(tape.gradient(sum(loss), logits), logits) (README.md:58-71) for
+ * wrt == CTC_AMD_WRT_LOGITS.  The reference's gamma tensor (classic_ctc_loss.py:167-308,
+ * simplified_ctc_loss.py:85-191) is never materialised.
+ */
+int ctc_amd_hessian(int kind, int wrt,
+                    const float *logits, const int32_t *labels, int label_stride,
+                    const int32_t *label_length, const int32_t *logit_length, int blank_index,
+                    int B, int T, int V, int U,
+                    float *loss, float *grad, float *hess,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTC_AMD_H */

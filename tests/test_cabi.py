@@ -1,0 +1,76 @@
+"""CPU-side checks of the drop-in boundary: libctc_amd.so loads, exports every symbol that include/ctc_amd.h
+declares, reports the header's ABI version, validates arguments without touching a GPU, and the product
+package never imports the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from tf_seq2seq_losses_amd import _lib
+    return _lib.load()
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "ctc_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ctc_amd_[a-z_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from tf_seq2seq_losses_amd import _lib
+    syms = _header_symbols()
+    assert len(syms) >= 6
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/ctc_amd.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in _lib.py"
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_abi_version_matches_header(lib):
+    text = open(os.path.join(ROOT, "include", "ctc_amd.h")).read()
+    ver = int(re.search(r"#define CTC_AMD_ABI_VERSION (\d+)", text).group(1))
+    assert lib.ctc_amd_abi_version() == ver
+
+
+def test_workspace_bytes_and_argument_errors(lib):
+    from tf_seq2seq_losses_amd import _lib
+    n = _lib.workspace_bytes(_lib.WS_LOSS_GRAD, _lib.CLASSIC, 256, 1000, 256, 128)
+    # emissions [B,T,UP+4] + alpha, beta [B,T+1,2*UP+4] + logp
+    assert n >= 256 * 1000 * 132 * 4 + 2 * 256 * 1001 * 260 * 4
+    assert _lib.workspace_bytes(_lib.WS_HESSIAN, _lib.SIMPLIFIED, 2, 5, 3, 4) > _lib.workspace_bytes(_lib.WS_LOSS_GRAD, _lib.SIMPLIFIED, 2, 5, 3, 4)
+    with pytest.raises(ValueError):
+        _lib.workspace_bytes(7, 0, 1, 1, 1, 1)
+    with pytest.raises(ValueError):
+        _lib.workspace_bytes(0, 0, 1, 1, 1, 100000)  # U beyond the supported maximum
+    # bad kind is rejected before anything is launched (no GPU needed for the validation path)
+    rc = lib.ctc_amd_loss_grad(5, 0, None, None, 0, None, None, 0, 1, 1, 3, 1, None, None, None, None, 0, None)
+    assert rc == _lib.EINVAL and b"kind" in lib.ctc_amd_last_error()
+    rc = lib.ctc_amd_loss_grad(0, 0, None, None, 0, None, None, 9, 1, 1, 3, 1, None, None, None, None, 0, None)
+    assert rc == _lib.EINVAL and b"blank" in lib.ctc_amd_last_error()
+    # B == 0 is not an error (tests/test_classic_ctc_loss.py:309-330)
+    assert lib.ctc_amd_loss_grad(0, 0, None, None, 0, None, None, 0, 0, 4, 3, 2, None, None, None, None, 0, None) == 0
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "tf_seq2seq_losses_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no CPU fallback", ""), f"{f} mentions the oracle"
+
+
+def test_cpu_tensors_fail_loudly():
+    import torch
+    import tf_seq2seq_losses_amd as ctc
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ctc.classic_ctc_loss(torch.zeros((1, 2), dtype=torch.int32), torch.zeros((1, 3, 4)),
+                             torch.zeros(1, dtype=torch.int32), torch.zeros(1, dtype=torch.int32))

@@ -1,0 +1,202 @@
+"""Parity of the HIP path (called through the C ABI via the Python mirror of the reference interface)
+against the oracle and the reference's known-answer table.  Needs a real MI355X: `pytest -m gpu`.
+
+Tolerances (north_star): 1e-4 absolute on gradient / Hessian entries and alpha/beta where
+finite, 1e-4 * max(1, |loss|) on the loss, demonstrated at the reference's own test sizes (T <= 64).
+Where the reference asserts exact float equality on a non-trivial value (loss == 100.0, == 1e10) the
+HIP path is granted 2 float32 ulps: it works in base-2 logarithms and converts once at the end.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctc_oracle as O
+from tests._cases import load_known_answers, case_inputs, check_case
+
+pytestmark = pytest.mark.gpu
+
+KA = load_known_answers()
+TOL = 1e-4
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _t(a):
+    return torch.as_tensor(np.asarray(a)).to(_dev())
+
+
+class _Np:
+    """numpy view of a loss-data object"""
+
+    def __init__(self, d):
+        self._d = d
+
+    def __getattr__(self, k):
+        return getattr(self._d, k).detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("case", KA["cases"], ids=[c["id"] for c in KA["cases"]])
+def test_known_answers(case):
+    import tf_seq2seq_losses_amd as ctc
+    inp = case_inputs(case)
+    cls = ctc.ClassicCtcLossData if case["kind"] == "classic" else ctc.SimplifiedCtcLossData
+    data = cls(_t(inp["labels"]), _t(inp["logprobas"]), _t(inp["label_length"]), _t(inp["logit_length"]), inp["blank"])
+    check_case(case, _Np(data), exact_ulps=2)
+
+
+@pytest.mark.parametrize("case", KA["shape_cases"], ids=[c["id"] for c in KA["shape_cases"]])
+def test_shape_cases(case):
+    import tf_seq2seq_losses_amd as ctc
+    B, T, V = case["logits_shape"]
+    logits = torch.full((B, T, V), case.get("logits_fill", 0.0), device=_dev(), requires_grad=True)
+    if "labels" in case:
+        labels, ll, tl = _t(np.int32(case["labels"])), _t(np.int32(case["label_length"])), _t(np.int32(case["logit_length"]))
+    else:
+        labels = torch.zeros(case["labels_shape"], dtype=torch.int32, device=_dev())
+        ll = torch.zeros(B, dtype=torch.int32, device=_dev())
+        tl = torch.zeros(B, dtype=torch.int32, device=_dev())
+    fn = ctc.classic_ctc_loss if case["kind"] == "classic" else ctc.simplified_ctc_loss
+    loss = fn(labels, logits, ll, tl, case.get("blank", 0))
+    assert list(loss.shape) == case.get("loss_shape", [B])
+    (g,) = torch.autograd.grad(loss.sum(), logits, create_graph="hessian_shape" in case, allow_unused=True)
+    if g is None:
+        g = torch.zeros_like(logits)
+    assert list(g.shape) == case.get("grad_shape", [B, T, V])
+    if "mean_loss" in case:
+        assert loss.mean().item() == float("inf")
+    if "hessian_shape" in case:
+        # README.md:58-71 : batch_jacobian of the gradient
+        H = torch.stack([torch.autograd.grad(g[:, t, k].sum(), logits, retain_graph=True)[0]
+                         for t in range(T) for k in range(V)], dim=1).reshape(B, T, V, T, V)
+        assert list(H.shape) == case["hessian_shape"]
+        ref = O.ctc_loss("classic", np.int32(case["labels"]), logits.detach().cpu().numpy(),
+                         np.int32(case["label_length"]), np.int32(case["logit_length"]), 0)
+        assert abs(loss[0].item() - 5 * np.log(3.0)) < 1e-5
+        assert np.abs(H.cpu().numpy() - O.logits_hessian(ref, logits.detach().cpu().numpy())).max() < TOL
+
+
+def _compare(kind, inp, blank=0, hess=True, ab=True):
+    import tf_seq2seq_losses_amd as ctc
+    fn = ctc.classic_ctc_loss if kind == "classic" else ctc.simplified_ctc_loss
+    x = _t(inp["logits"]).requires_grad_(True)
+    args = (_t(inp["labels"]), _t(inp["label_length"]), _t(inp["logit_length"]))
+    loss = fn(args[0], x, args[1], args[2], blank)
+    (g,) = torch.autograd.grad(loss.sum(), x)
+    ref = O.ctc_loss(kind, inp["labels"], inp["logits"], inp["label_length"], inp["logit_length"], blank)
+    lossn = loss.detach().cpu().numpy()
+    fin = np.isfinite(ref.loss)
+    assert np.array_equal(np.isfinite(lossn), fin), (lossn, ref.loss)
+    assert np.all(lossn[~fin] == np.inf)
+    if fin.any():
+        assert (np.abs(lossn[fin] - ref.loss[fin]) / np.maximum(1, np.abs(ref.loss[fin]))).max() < TOL
+    assert np.abs(g.cpu().numpy() - O.logits_gradient(ref, inp["logits"])).max() < TOL
+    # log-probability space objects
+    cls = ctc.ClassicCtcLossData if kind == "classic" else ctc.SimplifiedCtcLossData
+    lp = torch.log_softmax(_t(inp["logits"]), dim=2)
+    data = cls(args[0], lp, args[1], args[2], blank)
+    refd = O.LOSS_DATA[kind](inp["labels"], lp.cpu().numpy(), inp["label_length"], inp["logit_length"], blank)
+    assert np.abs(data.gradient.cpu().numpy() - refd.gradient).max() < TOL
+    if ab:
+        for name in ("alpha", "beta"):
+            a = getattr(data, name).cpu().numpy().astype(np.float64)
+            r = getattr(refd, name)
+            assert a.shape == r.shape, (name, a.shape, r.shape)
+            assert np.array_equal(np.isfinite(a), np.isfinite(r)), name
+            m = np.isfinite(r)
+            assert (np.abs(a[m] - r[m]) / np.maximum(1, np.abs(r[m]))).max() < TOL, name
+    if hess:
+        assert np.abs(data.hessian.cpu().numpy() - refd.hessian).max() < TOL
+        from tf_seq2seq_losses_amd import ops, _lib
+        p = ops.Prepared(args[0], _t(inp["logits"]), args[1], args[2], blank)
+        _, _, hx = ops.hessian(ops.KINDS[kind], _lib.WRT_LOGITS, p)
+        assert np.abs(hx.cpu().numpy() - O.logits_hessian(ref, inp["logits"])).max() < TOL
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+@pytest.mark.parametrize("B,T,V,seed", [(8, 20, 8, 0), (8, 64, 10, 1), (3, 12, 5, 2), (2, 4, 2, 3), (5, 33, 7, 4)])
+def test_random_reference_sizes(kind, B, T, V, seed):
+    """Sizes of the reference's own cross-implementation tests (tests/test_classic_ctc_loss.py:332-393,
+    tests/test_hessian.py:149-183), inputs in the distribution of tests/common.py:53-104 (ragged lengths,
+    label tensor wider than any label, some infeasible samples)."""
+    inp = O.generate_ctc_loss_inputs(B, T, seed, V)
+    _compare(kind, inp, hess=(T <= 33))
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+@pytest.mark.parametrize("T,V,U", [(40, 12, 17), (150, 33, 70), (200, 6, 130), (300, 9, 260)])
+def test_label_lengths_across_lane_tilings(kind, T, V, U):
+    """U = 17 / 70 / 130 / 260 exercise 1, 2, 4 and 8 label positions per lane (NL) and repeated tokens."""
+    inp = O.generate_ctc_loss_inputs(3, T, U, V, max_label_length=U)
+    inp["labels"][0, : U // 2] = 1  # long run of repeats (classic needs blanks in between)
+    _compare(kind, inp, hess=False)
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_nonzero_blank_and_odd_vocab(kind):
+    rng = np.random.default_rng(7)
+    B, T, V, U, blank = 4, 25, 11, 6, 3
+    labels = rng.integers(0, V - 1, (B, U)).astype(np.int32)
+    labels[labels >= blank] += 1  # never the blank
+    inp = dict(logits=rng.standard_normal((B, T, V)).astype(np.float32), labels=labels,
+               label_length=np.array([6, 3, 0, 5], dtype=np.int32), logit_length=np.array([25, 10, 7, 0], dtype=np.int32))
+    _compare(kind, inp, blank=blank)
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_extreme_logits(kind):
+    """README.md:74-78 : logits ~1e10 and -inf stay finite/sane."""
+    import tf_seq2seq_losses_amd as ctc
+    fn = ctc.classic_ctc_loss if kind == "classic" else ctc.simplified_ctc_loss
+    x = np.zeros((2, 6, 4), dtype=np.float32)
+    x[0, :, 1] = 1e10
+    x[1, :, 3] = -np.inf
+    x[1, 2, :] = [-np.inf, 0.0, -np.inf, -np.inf]
+    inp = dict(logits=x, labels=np.array([[1, 2], [1, 2]], dtype=np.int32), label_length=np.array([2, 1], dtype=np.int32),
+               logit_length=np.array([6, 6], dtype=np.int32))
+    xt = _t(x).requires_grad_(True)
+    loss = fn(_t(inp["labels"]), xt, _t(inp["label_length"]), _t(inp["logit_length"]), 0)
+    (g,) = torch.autograd.grad(loss.sum(), xt)
+    ref = O.ctc_loss(kind, inp["labels"], x, inp["label_length"], inp["logit_length"], 0)
+    ln = loss.detach().cpu().numpy()
+    assert np.isfinite(ln).all() and np.isfinite(g.cpu().numpy()).all()
+    assert (np.abs(ln - ref.loss) / np.maximum(1, np.abs(ref.loss))).max() < 1e-6
+    assert np.abs(g.cpu().numpy() - O.logits_gradient(ref, x)).max() < TOL
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_autograd_first_and_second_order(kind):
+    """d_loss weighting (base_loss.py:150-153), Hessian contraction (base_loss.py:167-173), third order refused
+    (base_loss.py:179-182)."""
+    import tf_seq2seq_losses_amd as ctc
+    fn = ctc.classic_ctc_loss if kind == "classic" else ctc.simplified_ctc_loss
+    inp = O.generate_ctc_loss_inputs(3, 9, 5, 4, max_label_length=3)
+    inp["logit_length"][:] = [9, 7, 8]
+    x = _t(inp["logits"]).requires_grad_(True)
+    w = torch.tensor([0.5, -2.0, 3.0], device=_dev())
+    loss = fn(_t(inp["labels"]), x, _t(inp["label_length"]), _t(inp["logit_length"]), 0)
+    (g,) = torch.autograd.grad((loss * w).sum(), x, create_graph=True)
+    ref = O.ctc_loss(kind, inp["labels"], inp["logits"], inp["label_length"], inp["logit_length"], 0)
+    gref = O.logits_gradient(ref, inp["logits"], d_loss=w.cpu().numpy())
+    assert np.abs(g.detach().cpu().numpy() - gref).max() < TOL
+    v = torch.randn_like(g)
+    (hv,) = torch.autograd.grad((g * v).sum(), x, create_graph=True)
+    href = np.einsum("btkuj,buj->btk", O.logits_hessian(ref, inp["logits"]), v.cpu().numpy()) * w.cpu().numpy()[:, None, None]
+    assert np.abs(hv.detach().cpu().numpy() - href).max() < TOL
+    with pytest.raises(NotImplementedError):
+        torch.autograd.grad(hv.sum(), x)
+
+
+def test_input_validation_matches_reference():
+    """base_loss.py:129-138 : AssertionError on rank / dtype / batch mismatch."""
+    import tf_seq2seq_losses_amd as ctc
+    good = dict(labels=torch.zeros((2, 3), dtype=torch.int32, device=_dev()), logits=torch.zeros((2, 5, 4), device=_dev()),
+                label_length=torch.zeros(2, dtype=torch.int32, device=_dev()), logit_length=torch.zeros(2, dtype=torch.int32, device=_dev()))
+    for key, bad in (("logits", torch.zeros((2, 5), device=_dev())), ("logits", torch.zeros((2, 5, 4), dtype=torch.float64, device=_dev())),
+                     ("labels", torch.zeros((3, 3), dtype=torch.int32, device=_dev())), ("label_length", torch.zeros((2, 1), dtype=torch.int32, device=_dev()))):
+        kw = dict(good); kw[key] = bad
+        with pytest.raises(AssertionError):
+            ctc.classic_ctc_loss(**kw)
+    with pytest.raises(RuntimeError):
+        ctc.classic_ctc_loss(good["labels"].cpu(), good["logits"].cpu(), good["label_length"].cpu(), good["logit_length"].cpu())

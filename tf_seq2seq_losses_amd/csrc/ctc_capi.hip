@@ -1,0 +1,147 @@
+// C ABI of libctc_amd.so (see include/ctc_amd.h for the contract of every entry point).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "ctc_amd.h"
+#include "ctc_common.h"
+
+namespace ctc {
+hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *loss, int ndir, hipStream_t st);
+hipError_t run_grad(const Problem &p, const Layout &L, char *ws, const float *d_loss, float *grad, hipStream_t st);
+hipError_t run_convert(const Problem &p, const Layout &L, char *ws, float *alpha_out, float *beta_out, hipStream_t st);
+size_t hessian_extra_bytes(int kind, int B, int T, int V, int U);
+hipError_t run_hessian(const Problem &p, const Layout &L, char *ws, const float *grad, float *hess, hipStream_t st);
+}  // namespace ctc
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+constexpr int MAX_U = 16 * 64;       // scan_kernel is instantiated for up to 16 label positions per lane
+constexpr int MAX_V_GRAD = 16 * 1024;  // one LDS token row per wavefront
+
+int check_common(int kind, int wrt, const float *logits, const int32_t *labels, int label_stride,
+                 const int32_t *label_length, const int32_t *logit_length, int blank, int B, int T, int V, int U) {
+  if (kind != CTC_AMD_CLASSIC && kind != CTC_AMD_SIMPLIFIED) return fail(CTC_AMD_EINVAL, "kind must be 0 (classic) or 1 (simplified), got %d", kind);
+  if (wrt != CTC_AMD_WRT_LOGITS && wrt != CTC_AMD_WRT_LOGPROBS) return fail(CTC_AMD_EINVAL, "wrt must be 0 (logits) or 1 (logprobs), got %d", wrt);
+  if (B < 0 || T < 0 || V <= 0 || U < 0 || label_stride < 0) return fail(CTC_AMD_EINVAL, "negative size: B=%d T=%d V=%d U=%d label_stride=%d", B, T, V, U, label_stride);
+  if (blank < 0 || blank >= V) return fail(CTC_AMD_EINVAL, "blank_index %d outside [0, %d)", blank, V);
+  if (U > MAX_U) return fail(CTC_AMD_EINVAL, "U=%d exceeds the supported maximum %d", U, MAX_U);
+  if (B > 0 && (!label_length || !logit_length)) return fail(CTC_AMD_EINVAL, "null length pointer");
+  if (B > 0 && T > 0 && !logits) return fail(CTC_AMD_EINVAL, "null logits pointer");
+  if (B > 0 && label_stride > 0 && !labels) return fail(CTC_AMD_EINVAL, "null labels pointer");
+  if (B > 65535 * 32767) return fail(CTC_AMD_EINVAL, "B too large");
+  return CTC_AMD_OK;
+}
+
+ctc::Problem make_problem(int kind, int wrt, const float *logits, const int32_t *labels, int label_stride,
+                          const int32_t *label_length, const int32_t *logit_length, int blank, int B, int T, int V, int U) {
+  ctc::Problem p;
+  p.logits = logits; p.labels = labels; p.label_length = label_length; p.logit_length = logit_length;
+  p.label_stride = label_stride; p.blank = blank; p.B = B; p.T = T; p.V = V; p.U = U; p.kind = kind; p.wrt = wrt;
+  return p;
+}
+
+int hip_fail(hipError_t e, const char *where) { return fail(CTC_AMD_EHIP, "%s: %s", where, hipGetErrorString(e)); }
+
+}  // namespace
+
+extern "C" {
+
+int ctc_amd_abi_version(void) { return CTC_AMD_ABI_VERSION; }
+
+const char *ctc_amd_last_error(void) { return g_err; }
+
+int ctc_amd_workspace_bytes(int what, int kind, int B, int T, int V, int U, size_t *out_bytes) {
+  if (!out_bytes) return fail(CTC_AMD_EINVAL, "out_bytes is null");
+  if (kind != 0 && kind != 1) return fail(CTC_AMD_EINVAL, "bad kind %d", kind);
+  if (B < 0 || T < 0 || V <= 0 || U < 0 || U > MAX_U) return fail(CTC_AMD_EINVAL, "bad shape B=%d T=%d V=%d U=%d", B, T, V, U);
+  size_t extra = 0;
+  if (what == CTC_AMD_WS_HESSIAN) extra = ctc::hessian_extra_bytes(kind, B, T, V, U);
+  else if (what != CTC_AMD_WS_LOSS_GRAD && what != CTC_AMD_WS_ALPHA_BETA) return fail(CTC_AMD_EINVAL, "bad workspace selector %d", what);
+  *out_bytes = ctc::make_layout(kind, B, T, U, extra).total;
+  return CTC_AMD_OK;
+}
+
+int ctc_amd_loss_grad(int kind, int wrt, const float *logits, const int32_t *labels, int label_stride,
+                      const int32_t *label_length, const int32_t *logit_length, int blank_index, int B, int T, int V,
+                      int U, float *loss, float *grad, const float *d_loss, void *workspace, size_t workspace_bytes,
+                      void *stream) {
+  int rc = check_common(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
+  if (rc) return rc;
+  if (B == 0) return CTC_AMD_OK;
+  if (!loss) return fail(CTC_AMD_EINVAL, "null loss pointer");
+  if (grad && V > MAX_V_GRAD) return fail(CTC_AMD_EINVAL, "V=%d exceeds the supported maximum %d for the gradient", V, MAX_V_GRAD);
+  ctc::Layout L = ctc::make_layout(kind, B, T, U, 0);
+  if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
+  ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = ctc::run_emit_scan(p, L, static_cast<char *>(workspace), loss, grad ? 2 : 1, st);
+  if (e != hipSuccess) return hip_fail(e, "emit/scan launch");
+  if (grad) {
+    e = ctc::run_grad(p, L, static_cast<char *>(workspace), d_loss, grad, st);
+    if (e != hipSuccess) return hip_fail(e, "grad launch");
+  }
+  return CTC_AMD_OK;
+}
+
+int ctc_amd_alpha_beta(int kind, int wrt, const float *logits, const int32_t *labels, int label_stride,
+                       const int32_t *label_length, const int32_t *logit_length, int blank_index, int B, int T, int V,
+                       int U, float *loss, float *alpha, float *beta, void *workspace, size_t workspace_bytes,
+                       void *stream) {
+  int rc = check_common(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
+  if (rc) return rc;
+  if (B == 0) return CTC_AMD_OK;
+  if (!loss || !alpha || !beta) return fail(CTC_AMD_EINVAL, "null output pointer");
+  ctc::Layout L = ctc::make_layout(kind, B, T, U, 0);
+  if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
+  ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = ctc::run_emit_scan(p, L, static_cast<char *>(workspace), loss, 2, st);
+  if (e != hipSuccess) return hip_fail(e, "emit/scan launch");
+  e = ctc::run_convert(p, L, static_cast<char *>(workspace), alpha, beta, st);
+  if (e != hipSuccess) return hip_fail(e, "convert launch");
+  return CTC_AMD_OK;
+}
+
+int ctc_amd_hessian(int kind, int wrt, const float *logits, const int32_t *labels, int label_stride,
+                    const int32_t *label_length, const int32_t *logit_length, int blank_index, int B, int T, int V,
+                    int U, float *loss, float *grad, float *hess, void *workspace, size_t workspace_bytes,
+                    void *stream) {
+  int rc = check_common(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
+  if (rc) return rc;
+  if (B == 0) return CTC_AMD_OK;
+  if (!loss || !hess) return fail(CTC_AMD_EINVAL, "null output pointer");
+  if (V > MAX_V_GRAD) return fail(CTC_AMD_EINVAL, "V=%d exceeds the supported maximum %d", V, MAX_V_GRAD);
+  ctc::Layout L = ctc::make_layout(kind, B, T, U, ctc::hessian_extra_bytes(kind, B, T, V, U));
+  if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
+  ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char *ws = static_cast<char *>(workspace);
+  hipError_t e = ctc::run_emit_scan(p, L, ws, loss, 2, st);
+  if (e != hipSuccess) return hip_fail(e, "emit/scan launch");
+  // the Hessian needs the log-probability-space gradient g = -posterior; it lives in the extra workspace region
+  float *g_lp = reinterpret_cast<float *>(ws + L.off_extra);
+  ctc::Problem plp = p;
+  plp.wrt = CTC_AMD_WRT_LOGPROBS;
+  // grad_kernel only reads emis/alpha/beta/logp; with wrt = LOGPROBS it writes -posterior
+  e = ctc::run_grad(plp, L, ws, nullptr, g_lp, st);
+  if (e != hipSuccess) return hip_fail(e, "posterior launch");
+  if (grad) {
+    e = ctc::run_grad(p, L, ws, nullptr, grad, st);
+    if (e != hipSuccess) return hip_fail(e, "grad launch");
+  }
+  e = ctc::run_hessian(p, L, ws, g_lp, hess, st);
+  if (e != hipSuccess) return hip_fail(e, "hessian launch");
+  return CTC_AMD_OK;
+}
+
+}  // extern "C"

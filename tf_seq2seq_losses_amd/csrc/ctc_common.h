@@ -1,0 +1,99 @@
+// Shared device helpers and workspace layout for the gfx950 CTC kernels.
+//
+// Numeric conventions used by every kernel in csrc/:
+//   * all lattice quantities are base-2 logarithms (v_exp_f32 / v_log_f32 are base-2 natively, so a
+//     two-argument log-sum-exp is max + log2(1 + exp2(min - max)): 6 VALU ops, 2 of them transcendental);
+//   * log(0) is the finite sentinel NEG = -1e30 instead of -inf, so (a - b) never produces NaN and the
+//     recursion needs no special-casing (tools.py:57-71 handles (-inf,-inf) with an explicit branch);
+//     anything below NEG_THR is reported as -inf at the boundary;
+//   * every stored lattice row carries the cumulative renormalisation offset that was subtracted from
+//     it, as a (hi, lo) float pair; true value = stored + hi + lo.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ctc {
+
+constexpr float NEG = -1.0e30f;
+constexpr float NEG_THR = -1.0e29f;
+constexpr float LOG2E = 1.44269504088896340736f;
+constexpr double LN2_D = 0.69314718055994530942;
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x); }
+
+// base-2 log(2^a + 2^b); operands are finite (sentinel instead of -inf).
+__device__ __forceinline__ float lse2(float a, float b) {
+  float m = fmaxf(a, b);
+  float d = fminf(a, b) - m;
+  return m + flog2(1.0f + fexp2(d));
+}
+
+// lane i receives x from lane i-1; lane 0 receives `fill` (DPP wave_shr:1, one VALU op, no LDS).
+__device__ __forceinline__ float from_prev_lane(float x, float fill) {
+  int v = __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x138, 0xf, 0xf, false);
+  return __int_as_float(v);
+}
+// lane i receives x from lane i+1; lane 63 receives `fill` (DPP wave_shl:1).
+__device__ __forceinline__ float from_next_lane(float x, float fill) {
+  int v = __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x130, 0xf, 0xf, false);
+  return __int_as_float(v);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+
+// One call's inputs (device pointers) and shapes.
+struct Problem {
+  const float *logits;
+  const int32_t *labels;
+  const int32_t *label_length;
+  const int32_t *logit_length;
+  int label_stride, blank, B, T, V, U, kind, wrt;
+};
+
+// Device workspace layout.  UP = 64*NL lattice slots (label positions) per utterance, NL per lane.
+//   emis  [B][T][ERS]      : E[0..UP) = log2 p(label[i] at frame t) (NEG beyond label_length), [UP] = log2 p(blank),
+//                            [UP+1] = log2 of the row's softmax denominator (0 for WRT_LOGPROBS)
+//   alpha [B][T+1][SRS]    : classic: pairs (closed, open) of label position l = i+1 at [2i, 2i+1], the l = 0 pair at
+//   beta                     [2UP, 2UP+1], offset (hi, lo) at [2UP+2, 2UP+3];  simplified: state l = i+1 at [i], l = 0 at
+//                            [UP], offset at [UP+2, UP+3]
+//   logp  [B] double       : log2 P(label | logits), -inf when infeasible
+struct Layout {
+  int NL, UP, ERS, SRS;
+  size_t off_emis, off_alpha, off_beta, off_logp, off_extra, total;
+};
+
+inline int nl_for(int U) {
+  int nl = 1;
+  while (nl * WAVE < U) nl *= 2;
+  return nl;
+}
+
+inline Layout make_layout(int kind, int B, int T, int U, size_t extra_bytes) {
+  Layout L;
+  L.NL = nl_for(U);
+  L.UP = L.NL * WAVE;
+  L.ERS = L.UP + 4;
+  L.SRS = (kind == 0 ? 2 * L.UP : L.UP) + 4;
+  auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+  size_t o = 0;
+  L.off_emis = o;  o = al(o + (size_t)B * T * L.ERS * 4);
+  L.off_alpha = o; o = al(o + (size_t)B * (T + 1) * L.SRS * 4);
+  L.off_beta = o;  o = al(o + (size_t)B * (T + 1) * L.SRS * 4);
+  L.off_logp = o;  o = al(o + (size_t)B * 8);
+  L.off_extra = o; o = al(o + extra_bytes);
+  L.total = o;
+  return L;
+}
+
+}  // namespace ctc

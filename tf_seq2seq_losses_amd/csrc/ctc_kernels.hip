@@ -1,0 +1,580 @@
+// gfx950 kernels of the CTC loss + gradient path (pipeline v1: emit -> scan -> grad).
+//
+//   emit_kernel : one wavefront per (b, t) frame.  Streams the logits row once, computes the softmax
+//                 normaliser with wave-shuffle reductions and gathers the U+1 emissions the lattice needs
+//                 (base_loss.py:59, 328-344, 365-393; classic_ctc_loss.py:464-563) into a compact row.
+//                 HBM-bound, V-independent output.
+//   scan_kernel : one wavefront per (utterance, direction).  The strictly sequential alpha / beta recursion
+//                 (classic_ctc_loss.py:310-462, simplified_ctc_loss.py:291-438; tools.py:191-277 is the
+//                 tf.while_loop it replaces) with the lattice row held in registers, NL label positions per
+//                 lane, neighbour exchange by one DPP wave shift, emission rows prefetched PF steps ahead.
+//   grad_kernel : one wavefront per (b, t) frame.  Posterior scatter into an LDS token row and the fused
+//                 softmax - posterior write (classic_ctc_loss.py:565-669, simplified_ctc_loss.py:456-534,
+//                 base_loss.py:262-298, 420-468 and TF's autodiff of tools.py:37-39).
+#include "ctc_common.h"
+
+namespace ctc {
+
+
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// ------------------------------------------------------------------------------------------------
+// emit
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void emit_kernel(Problem p, Layout L, float *__restrict__ emis) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)p.B * p.T) return;
+  const int b = (int)(row / p.T), t = (int)(row % p.T);
+  const int len = clampi(p.logit_length[b], 0, p.T);
+  if (t >= len) return;  // padded frames are never read downstream
+  const int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  const float *x = p.logits + row * (long)p.V;
+  const int V = p.V;
+
+  float mx = -INFINITY, sum = 0.f, log2sum = 0.f;
+  if (p.wrt == 0) {
+    if ((V & 3) == 0) {
+      for (int k = lane * 4; k < V; k += 256) {
+        float4 v = *reinterpret_cast<const float4 *>(x + k);
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+      }
+      mx = wave_max(mx);
+      const float mref = (mx == -INFINITY) ? 0.f : mx;
+      for (int k = lane * 4; k < V; k += 256) {
+        float4 v = *reinterpret_cast<const float4 *>(x + k);
+        sum += fexp2((v.x - mref) * LOG2E) + fexp2((v.y - mref) * LOG2E) + fexp2((v.z - mref) * LOG2E) +
+               fexp2((v.w - mref) * LOG2E);
+      }
+    } else {
+      for (int k = lane; k < V; k += 64) mx = fmaxf(mx, x[k]);
+      mx = wave_max(mx);
+      const float mref = (mx == -INFINITY) ? 0.f : mx;
+      for (int k = lane; k < V; k += 64) sum += fexp2((x[k] - mref) * LOG2E);
+    }
+    sum = wave_sum(sum);
+    log2sum = flog2(sum);  // -inf when the whole row is -inf: every emission becomes NEG below
+    if (mx == -INFINITY) mx = 0.f;
+  } else {
+    mx = 0.f;
+    log2sum = 0.f;
+  }
+  // log2 p(token k) = (x[k] - mx) * log2e - log2sum  (one rounding chain, no cancellation for huge logits)
+  float *erow = emis + row * (long)L.ERS;
+  for (int i = lane; i < L.UP; i += 64) {
+    float e = NEG;
+    if (i < ll) {
+      int tok = (i < p.label_stride) ? p.labels[(long)b * p.label_stride + i] : p.blank;
+      if (tok >= 0 && tok < V) e = fmaxf((x[tok] - mx) * LOG2E - log2sum, NEG);
+      if (!(e == e)) e = NEG;
+    }
+    erow[i] = e;
+  }
+  if (lane == 0) {
+    float bl = NEG;
+    if (p.blank >= 0 && p.blank < V) bl = fmaxf((x[p.blank] - mx) * LOG2E - log2sum, NEG);
+    if (!(bl == bl)) bl = NEG;
+    erow[L.UP] = bl;
+    erow[L.UP + 1] = mx * LOG2E + log2sum;  // log2 sum_k exp(x_k)
+    erow[L.UP + 2] = 0.f;
+    erow[L.UP + 3] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scan
+// ------------------------------------------------------------------------------------------------
+template <int NL>
+struct ERow {
+  float y[NL];
+  float bl;
+};
+
+template <int NL>
+__device__ __forceinline__ void load_erow(ERow<NL> &r, const float *__restrict__ base, int lane, int UP) {
+  const float *p = base + lane * NL;
+  if constexpr (NL == 1) {
+    r.y[0] = p[0];
+  } else if constexpr (NL == 2) {
+    float2 v = *reinterpret_cast<const float2 *>(p);
+    r.y[0] = v.x; r.y[1] = v.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < NL / 4; ++q) {
+      float4 v = *reinterpret_cast<const float4 *>(p + 4 * q);
+      r.y[4 * q] = v.x; r.y[4 * q + 1] = v.y; r.y[4 * q + 2] = v.z; r.y[4 * q + 3] = v.w;
+    }
+  }
+  r.bl = base[UP];
+}
+
+// store NL consecutive (a, b) pairs of this lane
+template <int NL>
+__device__ __forceinline__ void store_pairs(float *__restrict__ row, int lane, const float (&a)[NL], const float (&b)[NL]) {
+  float *p = row + 2 * lane * NL;
+  if constexpr (NL == 1) {
+    *reinterpret_cast<float2 *>(p) = make_float2(a[0], b[0]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < NL / 2; ++q)
+      *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(a[2 * q], b[2 * q], a[2 * q + 1], b[2 * q + 1]);
+  }
+}
+template <int NL>
+__device__ __forceinline__ void store_singles(float *__restrict__ row, int lane, const float (&a)[NL]) {
+  float *p = row + lane * NL;
+  if constexpr (NL == 1) {
+    p[0] = a[0];
+  } else if constexpr (NL == 2) {
+    *reinterpret_cast<float2 *>(p) = make_float2(a[0], a[1]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < NL / 4; ++q)
+      *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+  }
+}
+
+constexpr int PF = 8;         // emission rows kept in flight per wave
+constexpr int RENORM = 16;    // steps between exact renormalisations of the lattice row
+
+// One wavefront: blockIdx.x = utterance, blockIdx.y = direction (0 alpha, 1 beta).
+// Slot i = lane*NL + j is label position i (token label[i]).
+//   classic alpha : c[j] = closed(l=i+1), o[j] = open(l=i+1), c0 = closed(l=0)            (classic_ctc_loss.py:415-462)
+//   classic beta  : c[j] = closed(l=i),   o[j] = open(l=i+1), cU = closed(l=UP)           (classic_ctc_loss.py:349-377)
+//   simplified alpha: c[j] = a(l=i+1), c0 = a(l=0); beta: c[j] = b(l=i), cU = b(l=UP)     (simplified_ctc_loss.py:327-438)
+// With y[i] = log p(label[i]) the classic transition tables of classic_ctc_loss.py:464-563 reduce to
+//   rep[l] = y[l-1],  yo[l] = y[l] unless label[l] == label[l-1]   (for labels free of the blank token).
+template <int KIND, int NL>
+__global__ __launch_bounds__(64) void scan_kernel(Problem p, Layout L, const float *__restrict__ emis,
+                                                   float *__restrict__ alpha, float *__restrict__ beta,
+                                                   double *__restrict__ logp, float *__restrict__ loss) {
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  const int dir = blockIdx.y;
+  const int T = p.T, UP = L.UP;
+  const int len = clampi(p.logit_length[b], 0, T);
+  int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  const bool feasible_shape = (ll <= p.U);
+  if (!feasible_shape) ll = 0;
+
+  // static per-slot flags: norep[j] <=> label[i] != label[i-1] (true for i == 0)
+  bool norep[NL], norep_next[NL];
+  if constexpr (KIND == 0) {
+    const int32_t *lab = p.labels + (long)b * p.label_stride;
+    auto tok = [&](int i) -> int { return (i >= 0 && i < ll) ? ((i < p.label_stride) ? lab[i] : p.blank) : -1 - (i < 0); };
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      int i = lane * NL + j;
+      norep[j] = (i == 0) || tok(i) != tok(i - 1);
+      norep_next[j] = tok(i + 1) != tok(i);
+    }
+  }
+
+  float *rows = (dir == 0 ? alpha : beta) + (long)b * (T + 1) * L.SRS;
+  const float *ebase = emis + (long)b * T * L.ERS;
+
+  float c[NL], o[NL];
+  float cx;  // alpha: state l = 0; beta: state l = UP
+  double off = 0.0;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) { c[j] = NEG; o[j] = NEG; }
+
+  auto store_row = [&](int t) {
+    float *row = rows + (long)t * L.SRS;
+    if constexpr (KIND == 0) {
+      if (dir == 0) {
+        store_pairs<NL>(row, lane, c, o);
+        if (lane == 0) {
+          float oh = (float)off;
+          *reinterpret_cast<float4 *>(row + 2 * UP) = make_float4(cx, NEG, oh, (float)(off - (double)oh));
+        }
+      } else {
+        float cs[NL];  // closed(l = i+1): next slot's c
+#pragma unroll
+        for (int j = 0; j < NL - 1; ++j) cs[j] = c[j + 1];
+        cs[NL - 1] = from_next_lane(c[0], cx);
+        store_pairs<NL>(row, lane, cs, o);
+        if (lane == 0) {
+          float oh = (float)off;
+          *reinterpret_cast<float4 *>(row + 2 * UP) = make_float4(c[0], c[0], oh, (float)(off - (double)oh));
+        }
+      }
+    } else {
+      if (dir == 0) {
+        store_singles<NL>(row, lane, c);
+        if (lane == 0) {
+          float oh = (float)off;
+          *reinterpret_cast<float4 *>(row + UP) = make_float4(cx, 0.f, oh, (float)(off - (double)oh));
+        }
+      } else {
+        float cs[NL];
+#pragma unroll
+        for (int j = 0; j < NL - 1; ++j) cs[j] = c[j + 1];
+        cs[NL - 1] = from_next_lane(c[0], cx);
+        store_singles<NL>(row, lane, cs);
+        if (lane == 0) {
+          float oh = (float)off;
+          *reinterpret_cast<float4 *>(row + UP) = make_float4(c[0], 0.f, oh, (float)(off - (double)oh));
+        }
+      }
+    }
+  };
+
+  // ---- initial row ----
+  if (dir == 0) {
+    cx = 0.f;  // alpha[0]: only (l=0, closed) is reachable (classic_ctc_loss.py:453-462, simplified_ctc_loss.py:426-438)
+  } else {
+    // beta[len]: one-hot at l = label_length, both states (classic_ctc_loss.py:366-377, simplified_ctc_loss.py:345-356)
+    cx = (ll == UP) ? 0.f : NEG;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      int i = lane * NL + j;
+      if (i == ll) c[j] = 0.f;
+      if constexpr (KIND == 0) { if (i == ll - 1) o[j] = 0.f; }
+    }
+  }
+  if (!feasible_shape) {
+    if (dir == 0 && lane == 0) { logp[b] = -INFINITY; loss[b] = INFINITY; }
+    return;
+  }
+  store_row(dir == 0 ? 0 : len);
+
+  // ---- sequential sweep, emission rows prefetched PF steps ahead in registers ----
+  auto erow_ptr = [&](int k) -> const float * {  // row consumed by step k
+    int kk = k < len ? k : len - 1;
+    int t = (dir == 0) ? kk : (len - 1 - kk);
+    return ebase + (long)t * L.ERS;
+  };
+  ERow<NL> buf[PF];
+  if (len > 0) {
+#pragma unroll
+    for (int d = 0; d < PF; ++d) load_erow<NL>(buf[d], erow_ptr(d), lane, UP);
+  }
+  for (int k0 = 0; k0 < len; k0 += PF) {
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+      const int k = k0 + d;
+      if (k < len) {
+        const ERow<NL> e = buf[d];
+        const float bl = e.bl;
+        if constexpr (KIND == 0) {
+          if (dir == 0) {
+            // alpha step (classic_ctc_loss.py:415-451)
+            float m[NL], x[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+              m[j] = lse2(c[j], o[j]);
+              x[j] = norep_next[j] ? m[j] : c[j];  // what position l+1 may continue from
+            }
+            float xin0 = from_prev_lane(x[NL - 1], cx);
+#pragma unroll
+            for (int j = NL - 1; j >= 0; --j) {
+              float xin = (j == 0) ? xin0 : x[j - 1];
+              o[j] = e.y[j] + lse2(o[j], xin);
+              c[j] = bl + m[j];
+            }
+            cx += bl;
+          } else {
+            // beta step (classic_ctc_loss.py:349-364)
+            float h[NL], ee[NL], pn[NL], x[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+              h[j] = bl + c[j];
+              ee[j] = e.y[j] + o[j];
+              pn[j] = lse2(h[j], ee[j]);
+              x[j] = norep[j] ? pn[j] : h[j];
+            }
+            cx += bl;
+            float xinl = from_next_lane(x[0], cx);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+              float xin = (j == NL - 1) ? xinl : x[j + 1];
+              o[j] = lse2(xin, ee[j]);
+              c[j] = pn[j];
+            }
+          }
+        } else {
+          if (dir == 0) {
+            // simplified alpha step (simplified_ctc_loss.py:393-424)
+            float pin0 = from_prev_lane(c[NL - 1], cx);
+#pragma unroll
+            for (int j = NL - 1; j >= 0; --j) {
+              float pin = (j == 0) ? pin0 : c[j - 1];
+              c[j] = lse2(bl + c[j], e.y[j] + pin);
+            }
+            cx += bl;
+          } else {
+            // simplified beta step (simplified_ctc_loss.py:327-343)
+            float nin = from_next_lane(c[0], cx);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+              float nx = (j == NL - 1) ? nin : c[j + 1];
+              c[j] = lse2(bl + c[j], e.y[j] + nx);
+            }
+            cx += bl;
+          }
+        }
+        if ((k & (RENORM - 1)) == RENORM - 1) {
+          float mx = cx;
+#pragma unroll
+          for (int j = 0; j < NL; ++j) {
+            mx = fmaxf(mx, c[j]);
+            if constexpr (KIND == 0) mx = fmaxf(mx, o[j]);
+          }
+          mx = wave_max(mx);
+          if (mx > NEG_THR) {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+              c[j] -= mx;
+              if constexpr (KIND == 0) o[j] -= mx;
+            }
+            cx -= mx;
+            off += (double)mx;
+          }
+        }
+        store_row(dir == 0 ? k + 1 : len - 1 - k);
+      }
+      if (k + PF < len) load_erow<NL>(buf[d], erow_ptr(k + PF), lane, UP);
+    }
+  }
+
+  if (dir == 0) {
+    // loss = -alpha[len, label_length] (classic_ctc_loss.py:152-165, simplified_ctc_loss.py:73-83)
+    float mine = NEG;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      int i = lane * NL + j;
+      if (i == ll - 1) mine = (KIND == 0) ? lse2(c[j], o[j]) : c[j];
+    }
+    float v = (ll == 0) ? cx : wave_max(mine);
+    if (lane == 0) {
+      if (v > NEG_THR) {
+        double lp2 = (double)v + off;
+        logp[b] = lp2;
+        loss[b] = (float)(-lp2 * LN2_D);
+      } else {
+        logp[b] = -INFINITY;
+        loss[b] = INFINITY;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// grad
+// ------------------------------------------------------------------------------------------------
+// Posterior of "frame t emits token k".  Classic: the lattice state at t+1 names the token emitted at t
+// (closed <=> blank, open(l) <=> label[l-1]), so post = sum over states of alpha[t+1] * beta[t+1] / P, which is
+// the regrouping of classic_ctc_loss.py:565-669.  Simplified: blank = bl * sum_l a[t,l] b[t+1,l],
+// token = sum_{i: label[i]=k} a[t,i] y[t,i] b[t+1,i+1] (simplified_ctc_loss.py:456-534).
+template <int KIND>
+__global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const float *__restrict__ emis,
+                                                    const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                    const double *__restrict__ logp, const float *__restrict__ d_loss,
+                                                    float *__restrict__ grad, int waves_per_block) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * waves_per_block + w;
+  if (row >= (long)p.B * p.T) return;
+  const int b = (int)(row / p.T), t = (int)(row % p.T);
+  const int V = p.V, UP = L.UP;
+  float *g = grad + row * (long)V;
+  const int len = clampi(p.logit_length[b], 0, p.T);
+  const double lp = logp[b];
+  if (t >= len || lp == -INFINITY) {
+    // padded frames and infeasible samples: exactly zero (base_loss.py:283-298)
+    if ((V & 3) == 0) for (int k = lane * 4; k < V; k += 256) *reinterpret_cast<float4 *>(g + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else for (int k = lane; k < V; k += 64) g[k] = 0.f;
+    return;
+  }
+  int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  float *bin = lds + (long)w * V;
+  for (int k = lane; k < V; k += 64) bin[k] = 0.f;
+  __builtin_amdgcn_wave_barrier();
+
+  const int32_t *lab = p.labels + (long)b * p.label_stride;
+  const float *ra = alpha + ((long)b * (p.T + 1) + (KIND == 0 ? t + 1 : t)) * L.SRS;
+  const float *rb = beta + ((long)b * (p.T + 1) + t + 1) * L.SRS;
+  const int offpos = (KIND == 0 ? 2 * UP : UP) + 2;
+  // alpha~ + beta~ + (offsets - log P) is summed in double: with logits ~1e10 the three addends are each ~1e10 and
+  // cancel to O(1) (README.md:74-78 promises sane outputs there); float addition would lose the result entirely.
+  const double scale = (double)ra[offpos] + (double)ra[offpos + 1] + (double)rb[offpos] + (double)rb[offpos + 1] - lp;
+  auto post = [&](float a_, float b_) -> float { return fexp2((float)((double)a_ + (double)b_ + scale)); };
+  auto post3 = [&](float a_, float b_, float c_) -> float { return fexp2((float)((double)a_ + (double)b_ + (double)c_ + scale)); };
+  float qblank = 0.f;
+  if constexpr (KIND == 0) {
+    for (int i = lane; i < UP; i += 64) {
+      float2 a = *reinterpret_cast<const float2 *>(ra + 2 * i);
+      float2 bb = *reinterpret_cast<const float2 *>(rb + 2 * i);
+      qblank += post(a.x, bb.x);
+      if (i < ll) {
+        float q = post(a.y, bb.y);
+        int tok = (i < p.label_stride) ? lab[i] : p.blank;
+        if (tok >= 0 && tok < V && tok != p.blank) atomicAdd(&bin[tok], q);
+      }
+    }
+    if (lane == 0) qblank += post(ra[2 * UP], rb[2 * UP]);
+  } else {
+    const float *er = emis + row * (long)L.ERS;
+    const float bl = er[UP];
+    for (int i = lane; i < UP; i += 64) {
+      float ai = ra[i], bi = rb[i];  // state l = i+1 in both rows
+      qblank += post3(ai, bi, bl);
+      if (i < ll) {
+        float aprev = (i == 0) ? ra[UP] : ra[i - 1];  // a[t, l = i]
+        float q = post3(aprev, er[i], bi);  // a[t, l=i] * y[t,i] * b[t+1, l=i+1]
+        int tok = (i < p.label_stride) ? lab[i] : p.blank;
+        if (tok >= 0 && tok < V && tok != p.blank) atomicAdd(&bin[tok], q);
+      }
+    }
+    if (lane == 0) qblank += post3(ra[UP], rb[UP], bl);
+  }
+  qblank = wave_sum(qblank);
+  if (lane == 0 && p.blank >= 0 && p.blank < V) bin[p.blank] = qblank;
+  __builtin_amdgcn_wave_barrier();
+
+  const float dl = d_loss ? d_loss[b] : 1.0f;
+  if (p.wrt == 0) {
+    // g_x[k] = d_loss * (softmax(x)[k] * sum_k' post[k'] - post[k]), sum_k' post = 1 on a valid frame of a feasible
+    // sample (TF autodiff of tools.py:37-39 applied to base_loss.py:150-153)
+    const float *x = p.logits + row * (long)V;
+    const float lse = emis[row * (long)L.ERS + UP + 1];
+    if ((V & 3) == 0) {
+      for (int k = lane * 4; k < V; k += 256) {
+        float4 v = *reinterpret_cast<const float4 *>(x + k);
+        float4 q = *reinterpret_cast<const float4 *>(bin + k);
+        float4 r;
+        r.x = dl * (fexp2(v.x * LOG2E - lse) - q.x);
+        r.y = dl * (fexp2(v.y * LOG2E - lse) - q.y);
+        r.z = dl * (fexp2(v.z * LOG2E - lse) - q.z);
+        r.w = dl * (fexp2(v.w * LOG2E - lse) - q.w);
+        *reinterpret_cast<float4 *>(g + k) = r;
+      }
+    } else {
+      for (int k = lane; k < V; k += 64) g[k] = dl * (fexp2(x[k] * LOG2E - lse) - bin[k]);
+    }
+  } else {
+    // gradient w.r.t. log-probabilities: -posterior (base_loss.py:262-268)
+    for (int k = lane; k < V; k += 64) g[k] = -dl * bin[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// convert: workspace rows -> the reference's alpha/beta tensors (natural log, -inf, padded frames filled in)
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ void convert_kernel(Problem p, Layout L, const float *__restrict__ ws_rows, int is_beta, float *__restrict__ out) {
+  const int S = (KIND == 0) ? 2 : 1;
+  const int Lr = p.U + 1;
+  const long n = (long)p.B * (p.T + 1) * Lr * S;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    int s = (int)(idx % S);
+    long r = idx / S;
+    int l = (int)(r % Lr); r /= Lr;
+    int t = (int)(r % (p.T + 1));
+    int b = (int)(r / (p.T + 1));
+    const int len = clampi(p.logit_length[b], 0, p.T);
+    int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+    float val;
+    if (ll > p.U) {
+      val = -INFINITY;
+    } else if (is_beta && t >= len) {
+      val = (l == ll) ? 0.f : -INFINITY;  // beta on padded frames: blank self-loops keep the one-hot
+    } else {
+      const int tt = t <= len ? t : len;
+      const float *row = ws_rows + ((long)b * (p.T + 1) + tt) * L.SRS;
+      const int offpos = (KIND == 0 ? 2 * L.UP : L.UP) + 2;
+      const double off = (double)row[offpos] + (double)row[offpos + 1];
+      float v;
+      if constexpr (KIND == 0) {
+        const int pos = (l == 0) ? 2 * L.UP : 2 * (l - 1);
+        if (t <= len) {
+          v = row[pos + s];
+        } else {
+          // alpha on padded frames: every state closes (blank with probability 1), open states die
+          v = (s == 0) ? lse2(row[pos], row[pos + 1]) : NEG;
+        }
+      } else {
+        const int pos = (l == 0) ? L.UP : (l - 1);
+        v = row[pos];
+      }
+      val = (v > NEG_THR) ? (float)(((double)v + off) * LN2_D) : -INFINITY;
+    }
+    out[idx] = val;
+  }
+}
+
+}  // namespace ctc
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers (called by the C ABI in ctc_capi.hip)
+// ------------------------------------------------------------------------------------------------
+namespace ctc {
+
+template <int KIND>
+static hipError_t launch_scan(const Problem &p, const Layout &L, const float *emis, float *alpha, float *beta,
+                              double *logp, float *loss, int ndir, hipStream_t st) {
+  dim3 grid(p.B, ndir), block(64);
+  switch (L.NL) {
+    case 1: hipLaunchKernelGGL((scan_kernel<KIND, 1>), grid, block, 0, st, p, L, emis, alpha, beta, logp, loss); break;
+    case 2: hipLaunchKernelGGL((scan_kernel<KIND, 2>), grid, block, 0, st, p, L, emis, alpha, beta, logp, loss); break;
+    case 4: hipLaunchKernelGGL((scan_kernel<KIND, 4>), grid, block, 0, st, p, L, emis, alpha, beta, logp, loss); break;
+    case 8: hipLaunchKernelGGL((scan_kernel<KIND, 8>), grid, block, 0, st, p, L, emis, alpha, beta, logp, loss); break;
+    case 16: hipLaunchKernelGGL((scan_kernel<KIND, 16>), grid, block, 0, st, p, L, emis, alpha, beta, logp, loss); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *loss, int ndir, hipStream_t st) {
+  float *emis = reinterpret_cast<float *>(ws + L.off_emis);
+  float *alpha = reinterpret_cast<float *>(ws + L.off_alpha);
+  float *beta = reinterpret_cast<float *>(ws + L.off_beta);
+  double *logp = reinterpret_cast<double *>(ws + L.off_logp);
+  const long rows = (long)p.B * p.T;
+  if (rows > 0) {
+    hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, L, emis);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (p.B == 0) return hipSuccess;
+  return p.kind == 0 ? launch_scan<0>(p, L, emis, alpha, beta, logp, loss, ndir, st)
+                     : launch_scan<1>(p, L, emis, alpha, beta, logp, loss, ndir, st);
+}
+
+hipError_t run_grad(const Problem &p, const Layout &L, char *ws, const float *d_loss, float *grad, hipStream_t st) {
+  const long rows = (long)p.B * p.T;
+  if (rows == 0) return hipSuccess;
+  const float *emis = reinterpret_cast<const float *>(ws + L.off_emis);
+  const float *alpha = reinterpret_cast<const float *>(ws + L.off_alpha);
+  const float *beta = reinterpret_cast<const float *>(ws + L.off_beta);
+  const double *logp = reinterpret_cast<const double *>(ws + L.off_logp);
+  int wpb = 4;
+  while (wpb > 1 && (size_t)wpb * p.V * 4 > 64 * 1024) wpb >>= 1;
+  const size_t shmem = (size_t)wpb * p.V * 4;
+  dim3 grid((unsigned)((rows + wpb - 1) / wpb)), block(64 * wpb);
+  if (p.kind == 0)
+    hipLaunchKernelGGL(grad_kernel<0>, grid, block, shmem, st, p, L, emis, alpha, beta, logp, d_loss, grad, wpb);
+  else
+    hipLaunchKernelGGL(grad_kernel<1>, grid, block, shmem, st, p, L, emis, alpha, beta, logp, d_loss, grad, wpb);
+  return hipGetLastError();
+}
+
+hipError_t run_convert(const Problem &p, const Layout &L, char *ws, float *alpha_out, float *beta_out, hipStream_t st) {
+  const long n = (long)p.B * (p.T + 1) * (p.U + 1) * (p.kind == 0 ? 2 : 1);
+  if (n == 0) return hipSuccess;
+  const float *alpha = reinterpret_cast<const float *>(ws + L.off_alpha);
+  const float *beta = reinterpret_cast<const float *>(ws + L.off_beta);
+  unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  if (p.kind == 0) {
+    hipLaunchKernelGGL(convert_kernel<0>, dim3(blocks), dim3(256), 0, st, p, L, alpha, 0, alpha_out);
+    hipLaunchKernelGGL(convert_kernel<0>, dim3(blocks), dim3(256), 0, st, p, L, beta, 1, beta_out);
+  } else {
+    hipLaunchKernelGGL(convert_kernel<1>, dim3(blocks), dim3(256), 0, st, p, L, alpha, 0, alpha_out);
+    hipLaunchKernelGGL(convert_kernel<1>, dim3(blocks), dim3(256), 0, st, p, L, beta, 1, beta_out);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace ctc

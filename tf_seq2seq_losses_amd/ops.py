@@ -1,0 +1,107 @@
+"""Thin torch<->C-ABI plumbing: device pointers, the current HIP stream and workspace allocation.
+torch is used for device memory and streams only; all arithmetic happens in libctc_amd.so."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+KINDS = {"classic": _lib.CLASSIC, "simplified": _lib.SIMPLIFIED}
+
+
+def _require_gpu(t: torch.Tensor) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            "tf_seq2seq_losses_amd runs on an AMD GPU only (HIP kernels for gfx950); got a CPU tensor and "
+            "there is no CPU fallback. Move the inputs to the GPU (tensor.cuda()).")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+class Prepared:
+    """Validated, contiguous device inputs of one call."""
+
+    def __init__(self, labels, x, label_length, logit_length, blank_index, U=None):
+        _require_gpu(x)
+        dev = x.device
+        self.x = x.contiguous()
+        self.labels = labels.to(device=dev, dtype=torch.int32).contiguous()
+        self.label_length = label_length.to(device=dev, dtype=torch.int32).contiguous()
+        self.logit_length = logit_length.to(device=dev, dtype=torch.int32).contiguous()
+        self.blank = int(blank_index)
+        self.B, self.T, self.V = (int(s) for s in x.shape)
+        self.stride = int(self.labels.shape[1])
+        # static bound on the label length: identical results to the reference's dynamic max(label_length)
+        # (base_loss.py:482-486) without a device->host sync
+        self.U = self.stride if U is None else int(U)
+        self.device = dev
+
+    def common(self, kind: int, wrt: int):
+        return (kind, wrt, _ptr(self.x), _ptr(self.labels), self.stride, _ptr(self.label_length),
+                _ptr(self.logit_length), self.blank, self.B, self.T, self.V, self.U)
+
+
+def _workspace(what: int, kind: int, p: Prepared) -> torch.Tensor:
+    n = _lib.workspace_bytes(what, kind, p.B, p.T, p.V, p.U)
+    return torch.empty(max(n, 1), dtype=torch.uint8, device=p.device)
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def loss_grad(kind: int, wrt: int, p: Prepared, want_grad: bool, d_loss: Optional[torch.Tensor] = None,
+              workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    lib = _lib.load()
+    loss = torch.empty(p.B, dtype=torch.float32, device=p.device)
+    grad = torch.empty((p.B, p.T, p.V), dtype=torch.float32, device=p.device) if want_grad else None
+    if p.B == 0:
+        return loss, grad
+    ws = workspace if workspace is not None else _workspace(_lib.WS_LOSS_GRAD, kind, p)
+    if d_loss is not None:
+        d_loss = d_loss.to(device=p.device, dtype=torch.float32).contiguous()
+    with torch.cuda.device(p.device):
+        rc = lib.ctc_amd_loss_grad(*p.common(kind, wrt), _ptr(loss), _ptr(grad), _ptr(d_loss),
+                                   ws.data_ptr(), ws.numel(), _stream(p.device))
+    _lib.check(rc, "ctc_amd_loss_grad")
+    return loss, grad
+
+
+def alpha_beta(kind: int, wrt: int, p: Prepared):
+    lib = _lib.load()
+    L = p.U + 1
+    shape = (p.B, p.T + 1, L, 2) if kind == _lib.CLASSIC else (p.B, p.T + 1, L)
+    loss = torch.empty(p.B, dtype=torch.float32, device=p.device)
+    alpha = torch.empty(shape, dtype=torch.float32, device=p.device)
+    beta = torch.empty(shape, dtype=torch.float32, device=p.device)
+    if p.B == 0:
+        return loss, alpha, beta
+    ws = _workspace(_lib.WS_ALPHA_BETA, kind, p)
+    with torch.cuda.device(p.device):
+        rc = lib.ctc_amd_alpha_beta(*p.common(kind, wrt), _ptr(loss), _ptr(alpha), _ptr(beta),
+                                    ws.data_ptr(), ws.numel(), _stream(p.device))
+    _lib.check(rc, "ctc_amd_alpha_beta")
+    return loss, alpha, beta
+
+
+def hessian(kind: int, wrt: int, p: Prepared, want_grad: bool = True):
+    lib = _lib.load()
+    loss = torch.empty(p.B, dtype=torch.float32, device=p.device)
+    grad = torch.empty((p.B, p.T, p.V), dtype=torch.float32, device=p.device) if want_grad else None
+    hess = torch.empty((p.B, p.T, p.V, p.T, p.V), dtype=torch.float32, device=p.device)
+    if p.B == 0 or p.T == 0:
+        if p.B and not p.T:
+            loss, _ = loss_grad(kind, wrt, p, False)
+        return loss, grad, hess
+    ws = _workspace(_lib.WS_HESSIAN, kind, p)
+    with torch.cuda.device(p.device):
+        rc = lib.ctc_amd_hessian(*p.common(kind, wrt), _ptr(loss), _ptr(grad), _ptr(hess),
+                                 ws.data_ptr(), ws.numel(), _stream(p.device))
+    _lib.check(rc, "ctc_amd_hessian")
+    return loss, grad, hess
