@@ -63,7 +63,7 @@ struct Problem {
 
 // Device workspace layout.  UP = 64*NL lattice slots (label positions) per utterance, NL per lane.
 //   emis  [B][T][ERS]      : E[0..UP) = log2 p(label[i] at frame t) (NEG beyond label_length), [UP] = log2 p(blank),
-//                            [UP+1] = log2 of the row's softmax denominator (0 for WRT_LOGPROBS)
+//                            [UP+1] = row max mx, [UP+2] = log2 sum_k exp(x_k - mx)  (both 0 for WRT_LOGPROBS)
 //   alpha [B][T+1][SRS]    : classic: pairs (closed, open) of label position l = i+1 at [2i, 2i+1], the l = 0 pair at
 //   beta                     [2UP, 2UP+1], offset (hi, lo) at [2UP+2, 2UP+3];  simplified: state l = i+1 at [i], l = 0 at
 //                            [UP], offset at [UP+2, UP+3]

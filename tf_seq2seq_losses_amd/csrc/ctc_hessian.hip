@@ -66,16 +66,17 @@ __global__ __launch_bounds__(256) void hess_upper_kernel(Problem p, Layout L, co
 
   // ---- diagonal block t2 == t1 (base_loss.py:205-221: set_diag with the log-gradient) ----
   {
-    float s1 = 0.f, lse = 0.f;
+    float s1 = 0.f, mx = 0.f, l2s = 0.f;
     const float *x = p.logits + ((long)b * T + t1) * V;
     if (p.wrt == 0) {
-      lse = emis[((long)b * T + t1) * L.ERS + UP + 1];
-      s1 = fexp2(x[k1] * LOG2E - lse);
+      mx = emis[((long)b * T + t1) * L.ERS + UP + 1];
+      l2s = emis[((long)b * T + t1) * L.ERS + UP + 2];
+      s1 = fexp2((x[k1] - mx) * LOG2E - l2s);
     }
     for (int k2 = lane; k2 < V; k2 += 64) {
       float val = g1 * grow[(long)t1 * V + k2] + (k2 == k1 ? g1 : 0.f);
       if (p.wrt == 0) {
-        float s2 = fexp2(x[k2] * LOG2E - lse);
+        float s2 = fexp2((x[k2] - mx) * LOG2E - l2s);
         val += (k2 == k1 ? s1 : 0.f) - s1 * s2;
       }
       out[(long)t1 * V + k2] = val;
@@ -130,8 +131,8 @@ __global__ __launch_bounds__(256) void hess_upper_kernel(Problem p, Layout L, co
     const float *rb = beta + ((long)b * (T + 1) + t2 + 1) * L.SRS;
     const int offpos = (KIND == 0 ? 2 * UP : UP) + 2;
     const double sc = voff + (double)rb[offpos] + (double)rb[offpos + 1] - lp;
-    auto post = [&](float a_, float b_) -> float { return fexp2((float)((double)a_ + (double)b_ + sc)); };
-    auto post3 = [&](float a_, float b_, float c_) -> float { return fexp2((float)((double)a_ + (double)b_ + (double)c_ + sc)); };
+    auto post = [&](float a_, float b_) -> float { return fminf(fexp2((float)((double)a_ + (double)b_ + sc)), 1.0f); };  // a posterior never exceeds 1
+    auto post3 = [&](float a_, float b_, float c_) -> float { return fminf(fexp2((float)((double)a_ + (double)b_ + (double)c_ + sc)), 1.0f); };
     const float bl = er[UP];
     float y[NL];
 #pragma unroll

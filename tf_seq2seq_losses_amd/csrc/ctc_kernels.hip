@@ -75,8 +75,9 @@ __global__ __launch_bounds__(256) void emit_kernel(Problem p, Layout L, float *_
     if (p.blank >= 0 && p.blank < V) bl = fmaxf((x[p.blank] - mx) * LOG2E - log2sum, NEG);
     if (!(bl == bl)) bl = NEG;
     erow[L.UP] = bl;
-    erow[L.UP + 1] = mx * LOG2E + log2sum;  // log2 sum_k exp(x_k)
-    erow[L.UP + 2] = 0.f;
+    // softmax(x)[k] = exp2((x[k] - mx) * log2e - log2sum); kept as two terms so that huge logits cancel exactly
+    erow[L.UP + 1] = mx;
+    erow[L.UP + 2] = log2sum;
     erow[L.UP + 3] = 0.f;
   }
 }
@@ -134,222 +135,220 @@ __device__ __forceinline__ void store_singles(float *__restrict__ row, int lane,
   }
 }
 
-constexpr int PF = 8;         // emission rows kept in flight per wave
-constexpr int RENORM = 16;    // steps between exact renormalisations of the lattice row
+constexpr int PF = 16;       // emission rows kept in flight per wave (= steps of one unrolled block)
+constexpr int RENORM = 16;   // steps between exact renormalisations of the lattice row (== PF: static position)
 
-// One wavefront: blockIdx.x = utterance, blockIdx.y = direction (0 alpha, 1 beta).
+// One wavefront: blockIdx.x = utterance; DIR 0 = alpha (forward in t), 1 = beta (backward).
 // Slot i = lane*NL + j is label position i (token label[i]).
-//   classic alpha : c[j] = closed(l=i+1), o[j] = open(l=i+1), c0 = closed(l=0)            (classic_ctc_loss.py:415-462)
-//   classic beta  : c[j] = closed(l=i),   o[j] = open(l=i+1), cU = closed(l=UP)           (classic_ctc_loss.py:349-377)
-//   simplified alpha: c[j] = a(l=i+1), c0 = a(l=0); beta: c[j] = b(l=i), cU = b(l=UP)     (simplified_ctc_loss.py:327-438)
+//   classic alpha : c[j] = closed(l=i+1), o[j] = open(l=i+1), cx = closed(l=0)            (classic_ctc_loss.py:415-462)
+//   classic beta  : c[j] = closed(l=i),   o[j] = open(l=i+1), cx = closed(l=UP)           (classic_ctc_loss.py:349-377)
+//   simplified alpha: c[j] = a(l=i+1), cx = a(l=0); beta: c[j] = b(l=i), cx = b(l=UP)     (simplified_ctc_loss.py:327-438)
 // With y[i] = log p(label[i]) the classic transition tables of classic_ctc_loss.py:464-563 reduce to
 //   rep[l] = y[l-1],  yo[l] = y[l] unless label[l] == label[l-1]   (for labels free of the blank token).
-template <int KIND, int NL>
-__global__ __launch_bounds__(64) void scan_kernel(Problem p, Layout L, const float *__restrict__ emis,
-                                                   float *__restrict__ alpha, float *__restrict__ beta,
-                                                   double *__restrict__ logp, float *__restrict__ loss) {
+// The steady-state loop is straight-line code (PF steps unrolled, no branches) so that hipcc emits counted
+// s_waitcnt vmcnt(N): each step waits only for the emission row issued PF steps earlier, never for the
+// prefetches and row stores still in flight.
+template <int KIND, int NL, int DIR>
+struct Scan {
+  float c[NL], o[NL], cx;
+  double off;
+  bool norep[NL], norep_next[NL];
+
+  __device__ __forceinline__ void step(const ERow<NL> &e) {
+    const float bl = e.bl;
+    if constexpr (KIND == 0 && DIR == 0) {
+      // alpha step (classic_ctc_loss.py:415-451)
+      float m[NL], x[NL];
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        m[j] = lse2(c[j], o[j]);
+        x[j] = norep_next[j] ? m[j] : c[j];  // what position l+1 may continue from
+      }
+      float xin0 = from_prev_lane(x[NL - 1], cx);
+#pragma unroll
+      for (int j = NL - 1; j >= 0; --j) {
+        float xin = (j == 0) ? xin0 : x[j - 1];
+        o[j] = e.y[j] + lse2(o[j], xin);
+        c[j] = bl + m[j];
+      }
+      cx += bl;
+    } else if constexpr (KIND == 0 && DIR == 1) {
+      // beta step (classic_ctc_loss.py:349-364)
+      float h[NL], ee[NL], pn[NL], x[NL];
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        h[j] = bl + c[j];
+        ee[j] = e.y[j] + o[j];
+        pn[j] = lse2(h[j], ee[j]);
+        x[j] = norep[j] ? pn[j] : h[j];
+      }
+      cx += bl;
+      float xinl = from_next_lane(x[0], cx);
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        float xin = (j == NL - 1) ? xinl : x[j + 1];
+        o[j] = lse2(xin, ee[j]);
+        c[j] = pn[j];
+      }
+    } else if constexpr (KIND == 1 && DIR == 0) {
+      // simplified alpha step (simplified_ctc_loss.py:393-424)
+      float pin0 = from_prev_lane(c[NL - 1], cx);
+#pragma unroll
+      for (int j = NL - 1; j >= 0; --j) {
+        float pin = (j == 0) ? pin0 : c[j - 1];
+        c[j] = lse2(bl + c[j], e.y[j] + pin);
+      }
+      cx += bl;
+    } else {
+      // simplified beta step (simplified_ctc_loss.py:327-343)
+      float nin = from_next_lane(c[0], cx);
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        float nx = (j == NL - 1) ? nin : c[j + 1];
+        c[j] = lse2(bl + c[j], e.y[j] + nx);
+      }
+      cx += bl;
+    }
+  }
+
+  // exact renormalisation: subtract the row maximum, remember it in `off` (branch-free)
+  __device__ __forceinline__ void renorm() {
+    float mx = cx;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      mx = fmaxf(mx, c[j]);
+      if constexpr (KIND == 0) mx = fmaxf(mx, o[j]);
+    }
+    mx = wave_max(mx);
+    mx = (mx > NEG_THR) ? mx : 0.f;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      c[j] -= mx;
+      if constexpr (KIND == 0) o[j] -= mx;
+    }
+    cx -= mx;
+    off += (double)mx;
+  }
+
+  // row layout: see Layout in ctc_common.h.  The 16-byte tail (l = 0 state + offset) is wave-uniform data
+  // written by every lane to the same address, which keeps the store branch-free.
+  __device__ __forceinline__ void store_row(float *__restrict__ row, int lane, int UP) const {
+    const float oh = (float)off;
+    const float ol = (float)(off - (double)oh);
+    if constexpr (DIR == 0) {
+      if constexpr (KIND == 0) {
+        store_pairs<NL>(row, lane, c, o);
+        *reinterpret_cast<float4 *>(row + 2 * UP) = make_float4(cx, NEG, oh, ol);
+      } else {
+        store_singles<NL>(row, lane, c);
+        *reinterpret_cast<float4 *>(row + UP) = make_float4(cx, 0.f, oh, ol);
+      }
+    } else {
+      float cs[NL];  // state of label position l = i+1 lives in the next slot's c
+#pragma unroll
+      for (int j = 0; j < NL - 1; ++j) cs[j] = c[j + 1];
+      cs[NL - 1] = from_next_lane(c[0], cx);
+      const float c00 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c[0])));  // state l = 0 (lane 0, slot 0)
+      if constexpr (KIND == 0) {
+        store_pairs<NL>(row, lane, cs, o);
+        *reinterpret_cast<float4 *>(row + 2 * UP) = make_float4(c00, c00, oh, ol);
+      } else {
+        store_singles<NL>(row, lane, cs);
+        *reinterpret_cast<float4 *>(row + UP) = make_float4(c00, 0.f, oh, ol);
+      }
+    }
+  }
+};
+
+template <int KIND, int NL, int DIR>
+__device__ __forceinline__ void scan_body(const Problem &p, const Layout &L, const float *__restrict__ emis,
+                                          float *__restrict__ rows_all, double *__restrict__ logp,
+                                          float *__restrict__ loss) {
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
-  const int dir = blockIdx.y;
   const int T = p.T, UP = L.UP;
   const int len = clampi(p.logit_length[b], 0, T);
   int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
-  const bool feasible_shape = (ll <= p.U);
-  if (!feasible_shape) ll = 0;
-
-  // static per-slot flags: norep[j] <=> label[i] != label[i-1] (true for i == 0)
-  bool norep[NL], norep_next[NL];
-  if constexpr (KIND == 0) {
+  if (ll > p.U) {  // contract violation: reported as an infeasible sample
+    if (DIR == 0 && lane == 0) { logp[b] = -INFINITY; loss[b] = INFINITY; }
+    return;
+  }
+  Scan<KIND, NL, DIR> S;
+  S.off = 0.0;
+  {
     const int32_t *lab = p.labels + (long)b * p.label_stride;
     auto tok = [&](int i) -> int { return (i >= 0 && i < ll) ? ((i < p.label_stride) ? lab[i] : p.blank) : -1 - (i < 0); };
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       int i = lane * NL + j;
-      norep[j] = (i == 0) || tok(i) != tok(i - 1);
-      norep_next[j] = tok(i + 1) != tok(i);
+      S.norep[j] = (i == 0) || tok(i) != tok(i - 1);
+      S.norep_next[j] = tok(i + 1) != tok(i);
+      S.c[j] = NEG;
+      S.o[j] = NEG;
     }
   }
-
-  float *rows = (dir == 0 ? alpha : beta) + (long)b * (T + 1) * L.SRS;
+  float *rows = rows_all + (long)b * (T + 1) * L.SRS;
   const float *ebase = emis + (long)b * T * L.ERS;
 
-  float c[NL], o[NL];
-  float cx;  // alpha: state l = 0; beta: state l = UP
-  double off = 0.0;
-#pragma unroll
-  for (int j = 0; j < NL; ++j) { c[j] = NEG; o[j] = NEG; }
-
-  auto store_row = [&](int t) {
-    float *row = rows + (long)t * L.SRS;
-    if constexpr (KIND == 0) {
-      if (dir == 0) {
-        store_pairs<NL>(row, lane, c, o);
-        if (lane == 0) {
-          float oh = (float)off;
-          *reinterpret_cast<float4 *>(row + 2 * UP) = make_float4(cx, NEG, oh, (float)(off - (double)oh));
-        }
-      } else {
-        float cs[NL];  // closed(l = i+1): next slot's c
-#pragma unroll
-        for (int j = 0; j < NL - 1; ++j) cs[j] = c[j + 1];
-        cs[NL - 1] = from_next_lane(c[0], cx);
-        store_pairs<NL>(row, lane, cs, o);
-        if (lane == 0) {
-          float oh = (float)off;
-          *reinterpret_cast<float4 *>(row + 2 * UP) = make_float4(c[0], c[0], oh, (float)(off - (double)oh));
-        }
-      }
-    } else {
-      if (dir == 0) {
-        store_singles<NL>(row, lane, c);
-        if (lane == 0) {
-          float oh = (float)off;
-          *reinterpret_cast<float4 *>(row + UP) = make_float4(cx, 0.f, oh, (float)(off - (double)oh));
-        }
-      } else {
-        float cs[NL];
-#pragma unroll
-        for (int j = 0; j < NL - 1; ++j) cs[j] = c[j + 1];
-        cs[NL - 1] = from_next_lane(c[0], cx);
-        store_singles<NL>(row, lane, cs);
-        if (lane == 0) {
-          float oh = (float)off;
-          *reinterpret_cast<float4 *>(row + UP) = make_float4(c[0], 0.f, oh, (float)(off - (double)oh));
-        }
-      }
-    }
-  };
-
   // ---- initial row ----
-  if (dir == 0) {
-    cx = 0.f;  // alpha[0]: only (l=0, closed) is reachable (classic_ctc_loss.py:453-462, simplified_ctc_loss.py:426-438)
+  if constexpr (DIR == 0) {
+    S.cx = 0.f;  // alpha[0]: only (l=0, closed) is reachable (classic_ctc_loss.py:453-462, simplified_ctc_loss.py:426-438)
   } else {
     // beta[len]: one-hot at l = label_length, both states (classic_ctc_loss.py:366-377, simplified_ctc_loss.py:345-356)
-    cx = (ll == UP) ? 0.f : NEG;
+    S.cx = (ll == UP) ? 0.f : NEG;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       int i = lane * NL + j;
-      if (i == ll) c[j] = 0.f;
-      if constexpr (KIND == 0) { if (i == ll - 1) o[j] = 0.f; }
+      if (i == ll) S.c[j] = 0.f;
+      if (KIND == 0 && i == ll - 1) S.o[j] = 0.f;
     }
   }
-  if (!feasible_shape) {
-    if (dir == 0 && lane == 0) { logp[b] = -INFINITY; loss[b] = INFINITY; }
-    return;
-  }
-  store_row(dir == 0 ? 0 : len);
+  S.store_row(rows + (long)(DIR == 0 ? 0 : len) * L.SRS, lane, UP);
 
-  // ---- sequential sweep, emission rows prefetched PF steps ahead in registers ----
-  auto erow_ptr = [&](int k) -> const float * {  // row consumed by step k
+  // step k consumes emission row t = k (alpha) / len-1-k (beta) and produces lattice row k+1 / len-1-k
+  auto erow_ptr = [&](int k) -> const float * {
     int kk = k < len ? k : len - 1;
-    int t = (dir == 0) ? kk : (len - 1 - kk);
+    int t = (DIR == 0) ? kk : (len - 1 - kk);
     return ebase + (long)t * L.ERS;
   };
-  ERow<NL> buf[PF];
+  auto out_row = [&](int k) -> float * { return rows + (long)(DIR == 0 ? k + 1 : len - 1 - k) * L.SRS; };
+
   if (len > 0) {
+    ERow<NL> buf[PF];
 #pragma unroll
     for (int d = 0; d < PF; ++d) load_erow<NL>(buf[d], erow_ptr(d), lane, UP);
-  }
-  for (int k0 = 0; k0 < len; k0 += PF) {
+    int k0 = 0;
+    for (; k0 + PF <= len; k0 += PF) {
+#pragma unroll
+      for (int d = 0; d < PF; ++d) {
+        S.step(buf[d]);
+        load_erow<NL>(buf[d], erow_ptr(k0 + d + PF), lane, UP);  // clamped: re-reads the last row near the end
+        if (d == RENORM - 1) S.renorm();
+        S.store_row(out_row(k0 + d), lane, UP);
+      }
+    }
+    // tail: fewer than PF steps left, their rows are already in buf[0 .. len-k0)
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
-      const int k = k0 + d;
-      if (k < len) {
-        const ERow<NL> e = buf[d];
-        const float bl = e.bl;
-        if constexpr (KIND == 0) {
-          if (dir == 0) {
-            // alpha step (classic_ctc_loss.py:415-451)
-            float m[NL], x[NL];
-#pragma unroll
-            for (int j = 0; j < NL; ++j) {
-              m[j] = lse2(c[j], o[j]);
-              x[j] = norep_next[j] ? m[j] : c[j];  // what position l+1 may continue from
-            }
-            float xin0 = from_prev_lane(x[NL - 1], cx);
-#pragma unroll
-            for (int j = NL - 1; j >= 0; --j) {
-              float xin = (j == 0) ? xin0 : x[j - 1];
-              o[j] = e.y[j] + lse2(o[j], xin);
-              c[j] = bl + m[j];
-            }
-            cx += bl;
-          } else {
-            // beta step (classic_ctc_loss.py:349-364)
-            float h[NL], ee[NL], pn[NL], x[NL];
-#pragma unroll
-            for (int j = 0; j < NL; ++j) {
-              h[j] = bl + c[j];
-              ee[j] = e.y[j] + o[j];
-              pn[j] = lse2(h[j], ee[j]);
-              x[j] = norep[j] ? pn[j] : h[j];
-            }
-            cx += bl;
-            float xinl = from_next_lane(x[0], cx);
-#pragma unroll
-            for (int j = 0; j < NL; ++j) {
-              float xin = (j == NL - 1) ? xinl : x[j + 1];
-              o[j] = lse2(xin, ee[j]);
-              c[j] = pn[j];
-            }
-          }
-        } else {
-          if (dir == 0) {
-            // simplified alpha step (simplified_ctc_loss.py:393-424)
-            float pin0 = from_prev_lane(c[NL - 1], cx);
-#pragma unroll
-            for (int j = NL - 1; j >= 0; --j) {
-              float pin = (j == 0) ? pin0 : c[j - 1];
-              c[j] = lse2(bl + c[j], e.y[j] + pin);
-            }
-            cx += bl;
-          } else {
-            // simplified beta step (simplified_ctc_loss.py:327-343)
-            float nin = from_next_lane(c[0], cx);
-#pragma unroll
-            for (int j = 0; j < NL; ++j) {
-              float nx = (j == NL - 1) ? nin : c[j + 1];
-              c[j] = lse2(bl + c[j], e.y[j] + nx);
-            }
-            cx += bl;
-          }
-        }
-        if ((k & (RENORM - 1)) == RENORM - 1) {
-          float mx = cx;
-#pragma unroll
-          for (int j = 0; j < NL; ++j) {
-            mx = fmaxf(mx, c[j]);
-            if constexpr (KIND == 0) mx = fmaxf(mx, o[j]);
-          }
-          mx = wave_max(mx);
-          if (mx > NEG_THR) {
-#pragma unroll
-            for (int j = 0; j < NL; ++j) {
-              c[j] -= mx;
-              if constexpr (KIND == 0) o[j] -= mx;
-            }
-            cx -= mx;
-            off += (double)mx;
-          }
-        }
-        store_row(dir == 0 ? k + 1 : len - 1 - k);
+      if (k0 + d < len) {
+        S.step(buf[d]);
+        S.store_row(out_row(k0 + d), lane, UP);
       }
-      if (k + PF < len) load_erow<NL>(buf[d], erow_ptr(k + PF), lane, UP);
     }
   }
 
-  if (dir == 0) {
+  if constexpr (DIR == 0) {
     // loss = -alpha[len, label_length] (classic_ctc_loss.py:152-165, simplified_ctc_loss.py:73-83)
     float mine = NEG;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       int i = lane * NL + j;
-      if (i == ll - 1) mine = (KIND == 0) ? lse2(c[j], o[j]) : c[j];
+      if (i == ll - 1) mine = (KIND == 0) ? lse2(S.c[j], S.o[j]) : S.c[j];
     }
-    float v = (ll == 0) ? cx : wave_max(mine);
+    float v = (ll == 0) ? S.cx : wave_max(mine);
     if (lane == 0) {
       if (v > NEG_THR) {
-        double lp2 = (double)v + off;
+        double lp2 = (double)v + S.off;
         logp[b] = lp2;
         loss[b] = (float)(-lp2 * LN2_D);
       } else {
@@ -400,8 +399,8 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
   // alpha~ + beta~ + (offsets - log P) is summed in double: with logits ~1e10 the three addends are each ~1e10 and
   // cancel to O(1) (README.md:74-78 promises sane outputs there); float addition would lose the result entirely.
   const double scale = (double)ra[offpos] + (double)ra[offpos + 1] + (double)rb[offpos] + (double)rb[offpos + 1] - lp;
-  auto post = [&](float a_, float b_) -> float { return fexp2((float)((double)a_ + (double)b_ + scale)); };
-  auto post3 = [&](float a_, float b_, float c_) -> float { return fexp2((float)((double)a_ + (double)b_ + (double)c_ + scale)); };
+  auto post = [&](float a_, float b_) -> float { return fminf(fexp2((float)((double)a_ + (double)b_ + scale)), 1.0f); };  // a posterior never exceeds 1
+  auto post3 = [&](float a_, float b_, float c_) -> float { return fminf(fexp2((float)((double)a_ + (double)b_ + (double)c_ + scale)), 1.0f); };
   float qblank = 0.f;
   if constexpr (KIND == 0) {
     for (int i = lane; i < UP; i += 64) {
@@ -439,20 +438,21 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
     // g_x[k] = d_loss * (softmax(x)[k] * sum_k' post[k'] - post[k]), sum_k' post = 1 on a valid frame of a feasible
     // sample (TF autodiff of tools.py:37-39 applied to base_loss.py:150-153)
     const float *x = p.logits + row * (long)V;
-    const float lse = emis[row * (long)L.ERS + UP + 1];
+    const float mx = emis[row * (long)L.ERS + UP + 1];
+    const float l2s = emis[row * (long)L.ERS + UP + 2];
     if ((V & 3) == 0) {
       for (int k = lane * 4; k < V; k += 256) {
         float4 v = *reinterpret_cast<const float4 *>(x + k);
         float4 q = *reinterpret_cast<const float4 *>(bin + k);
         float4 r;
-        r.x = dl * (fexp2(v.x * LOG2E - lse) - q.x);
-        r.y = dl * (fexp2(v.y * LOG2E - lse) - q.y);
-        r.z = dl * (fexp2(v.z * LOG2E - lse) - q.z);
-        r.w = dl * (fexp2(v.w * LOG2E - lse) - q.w);
+        r.x = dl * (fexp2((v.x - mx) * LOG2E - l2s) - q.x);
+        r.y = dl * (fexp2((v.y - mx) * LOG2E - l2s) - q.y);
+        r.z = dl * (fexp2((v.z - mx) * LOG2E - l2s) - q.z);
+        r.w = dl * (fexp2((v.w - mx) * LOG2E - l2s) - q.w);
         *reinterpret_cast<float4 *>(g + k) = r;
       }
     } else {
-      for (int k = lane; k < V; k += 64) g[k] = dl * (fexp2(x[k] * LOG2E - lse) - bin[k]);
+      for (int k = lane; k < V; k += 64) g[k] = dl * (fexp2((x[k] - mx) * LOG2E - l2s) - bin[k]);
     }
   } else {
     // gradient w.r.t. log-probabilities: -posterior (base_loss.py:262-268)
@@ -512,16 +512,31 @@ __global__ void convert_kernel(Problem p, Layout L, const float *__restrict__ ws
 // ------------------------------------------------------------------------------------------------
 namespace ctc {
 
+// grid (B, ndir): blockIdx.y = 0 runs the alpha sweep, 1 the beta sweep.  The two sweeps are independent
+// (beta never reads alpha), so one launch puts both wavefronts of an utterance on the chip at once.
+template <int KIND, int NL>
+__global__ __launch_bounds__(64) void scan_kernel(Problem p, Layout L, const float *__restrict__ emis,
+                                                   float *__restrict__ alpha, float *__restrict__ beta,
+                                                   double *__restrict__ logp, float *__restrict__ loss) {
+  if (blockIdx.y == 0) scan_body<KIND, NL, 0>(p, L, emis, alpha, logp, loss);
+  else scan_body<KIND, NL, 1>(p, L, emis, beta, logp, loss);
+}
+
+template <int KIND, int NL>
+static void launch_scan_nl(const Problem &p, const Layout &L, const float *emis, float *alpha, float *beta, double *logp,
+                           float *loss, int ndir, hipStream_t st) {
+  hipLaunchKernelGGL((scan_kernel<KIND, NL>), dim3(p.B, ndir), dim3(64), 0, st, p, L, emis, alpha, beta, logp, loss);
+}
+
 template <int KIND>
 static hipError_t launch_scan(const Problem &p, const Layout &L, const float *emis, float *alpha, float *beta,
                               double *logp, float *loss, int ndir, hipStream_t st) {
-  dim3 grid(p.B, ndir), block(64);
   switch (L.NL) {
-    case 1: hipLaunchKernelGGL((scan_kernel<KIND, 1>), grid, block, 0, st, p, L, emis, alpha, beta, logp, loss); break;
-    case 2: hipLaunchKernelGGL((scan_kernel<KIND, 2>), grid, block, 0, st, p, L, emis, alpha, beta, logp, loss); break;
-    case 4: hipLaunchKernelGGL((scan_kernel<KIND, 4>), grid, block, 0, st, p, L, emis, alpha, beta, logp, loss); break;
-    case 8: hipLaunchKernelGGL((scan_kernel<KIND, 8>), grid, block, 0, st, p, L, emis, alpha, beta, logp, loss); break;
-    case 16: hipLaunchKernelGGL((scan_kernel<KIND, 16>), grid, block, 0, st, p, L, emis, alpha, beta, logp, loss); break;
+    case 1: launch_scan_nl<KIND, 1>(p, L, emis, alpha, beta, logp, loss, ndir, st); break;
+    case 2: launch_scan_nl<KIND, 2>(p, L, emis, alpha, beta, logp, loss, ndir, st); break;
+    case 4: launch_scan_nl<KIND, 4>(p, L, emis, alpha, beta, logp, loss, ndir, st); break;
+    case 8: launch_scan_nl<KIND, 8>(p, L, emis, alpha, beta, logp, loss, ndir, st); break;
+    case 16: launch_scan_nl<KIND, 16>(p, L, emis, alpha, beta, logp, loss, ndir, st); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
