@@ -48,28 +48,29 @@ def make_inputs(B, T, U, V, seed, ragged, device):
     return host, dev
 
 
-def cpu_baseline(kind, host, budget_s=20.0):
-    """Times the oracle (fp32 arithmetic, like the reference) on the first few utterances of the workload."""
-    from oracle import ctc_oracle as O
-    n = 2
-    t0 = time.perf_counter()
-    d = O.ctc_loss(kind, host["labels"][:n], host["logits"][:n], host["label_length"][:n], host["logit_length"][:n], 0,
-                   dtype=np.float32)
-    _ = d.loss
-    _ = O.logits_gradient(d, host["logits"][:n])
-    dt = time.perf_counter() - t0
-    # one more, larger sample if the first one was quick
-    n2 = int(max(n, min(host["logits"].shape[0], n * budget_s / max(dt, 1e-3) / 2)))
-    if n2 > n:
+def cpu_baseline(kind, host, budget_s=15.0):
+    """Times the C restatement of the reference's algorithm (oracle/ctc_oracle.c, float32 like the reference,
+    OpenMP over the batch) on the host cores, on a bounded sample of the same workload."""
+    from oracle import c_oracle as C
+    cores = os.cpu_count() or 1
+    threads = min(cores, C.num_threads())
+    B = host["logits"].shape[0]
+    n = min(B, max(threads, 8))
+
+    def run(m):
         t0 = time.perf_counter()
-        d = O.ctc_loss(kind, host["labels"][:n2], host["logits"][:n2], host["label_length"][:n2],
-                       host["logit_length"][:n2], 0, dtype=np.float32)
-        _ = d.loss
-        _ = O.logits_gradient(d, host["logits"][:n2])
-        dt = time.perf_counter() - t0
-        n = n2
-    return dict(value=n / dt, unit="utterances/s", cores=1, kind="port",
-                sample=f"oracle/ctc_oracle.py (NumPy fp32, 1 thread) loss+grad on the first {n} utterances of the workload, {dt:.1f} s")
+        C.loss_grad(kind, host["labels"][:m], host["logits"][:m], host["label_length"][:m], host["logit_length"][:m], 0,
+                    precision="f32", want_grad=True, n_threads=threads)
+        return time.perf_counter() - t0
+
+    dt = run(n)
+    n2 = int(min(B, max(n, n * budget_s / max(dt, 1e-3))))
+    n2 -= n2 % threads if n2 >= threads else 0
+    if n2 > n:
+        n, dt = n2, run(n2)
+    return dict(value=n / dt, unit="utterances/s", cores=threads, kind="port",
+                sample=f"oracle/ctc_oracle.c (C restatement of the reference's log-space alpha/beta + gradient, float32, "
+                       f"OpenMP {threads} threads of {cores} host cores) loss+grad on the first {n} utterances of the workload, {dt:.1f} s")
 
 
 def main():

@@ -1,0 +1,52 @@
+"""World-size-2 test of the batch-sharded path on CPU (gloo).  The per-rank compute is the oracle here (the HIP
+kernels need a GPU); what is under test is the sharding arithmetic and the single scalar all-reduce of
+tf_seq2seq_losses_amd/dist.py, i.e. everything the N > 1 bench path adds to the N = 1 path."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ctc_oracle as O
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _oracle_loss(labels, logits, label_length, logit_length, blank_index=0):
+    return torch.from_numpy(O.classic_ctc_loss(labels.numpy(), logits.numpy(), label_length.numpy(),
+                                                logit_length.numpy(), blank_index)).float()
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tf_seq2seq_losses_amd import dist as cdist
+    inp = O.generate_ctc_loss_inputs(7, 16, 11, 6)  # 7 utterances over 2 ranks: shards of 4 and 3
+    t = {k: torch.from_numpy(np.asarray(v)) for k, v in inp.items() if k != "blank_index"}
+    local, s, n = cdist.sharded_loss(_oracle_loss, t["labels"], t["logits"], t["label_length"], t["logit_length"], 0)
+    lo, hi = cdist.shard_bounds(7, rank, world)
+    out[rank] = (lo, hi, local.numpy().copy(), float(s), float(n))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_scalar_allreduce():
+    from tf_seq2seq_losses_amd import dist as cdist
+    assert [cdist.shard_bounds(7, r, 2) for r in range(2)] == [(0, 4), (4, 7)]
+    assert [cdist.shard_bounds(256, r, 8) for r in range(8)] == [(32 * r, 32 * r + 32) for r in range(8)]
+    assert [cdist.shard_bounds(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    inp = O.generate_ctc_loss_inputs(7, 16, 11, 6)
+    full = O.classic_ctc_loss(inp["labels"], inp["logits"], inp["label_length"], inp["logit_length"], 0)
+    fin = np.isfinite(full)
+    got = np.concatenate([out[0][2], out[1][2]])
+    assert (out[0][0], out[0][1], out[1][0], out[1][1]) == (0, 4, 4, 7)
+    assert np.array_equal(np.isfinite(got), fin) and np.abs(got[fin] - full[fin]).max() < 1e-4
+    for r in range(2):
+        assert abs(out[r][3] - full[fin].sum()) < 1e-3 and out[r][4] == fin.sum()

@@ -10,7 +10,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libctc_amd.so")
+LIB_PATH = os.environ.get("CTC_AMD_LIB", os.path.join(_HERE, "libctc_amd.so"))  # override: kernel experiments only
 
 ABI_VERSION = 1
 CLASSIC, SIMPLIFIED = 0, 1

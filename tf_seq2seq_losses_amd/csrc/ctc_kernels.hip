@@ -324,7 +324,9 @@ __device__ __forceinline__ void scan_body(const Problem &p, const Layout &L, con
         S.step(buf[d]);
         load_erow<NL>(buf[d], erow_ptr(k0 + d + PF), lane, UP);  // clamped: re-reads the last row near the end
         if (d == RENORM - 1) S.renorm();
+#ifndef CTC_EXPERIMENT_NO_STORE
         S.store_row(out_row(k0 + d), lane, UP);
+#endif
       }
     }
     // tail: fewer than PF steps left, their rows are already in buf[0 .. len-k0)
