@@ -1,6 +1,7 @@
 // C ABI of libctc_amd.so (see include/ctc_amd.h for the contract of every entry point).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "ctc_amd.h"
 #include "ctc_common.h"
@@ -9,6 +10,15 @@ namespace ctc {
 hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *loss, int ndir, hipStream_t st);
 hipError_t run_grad(const Problem &p, const Layout &L, char *ws, const float *d_loss, float *grad, hipStream_t st);
 hipError_t run_convert(const Problem &p, const Layout &L, char *ws, float *alpha_out, float *beta_out, hipStream_t st);
+hipError_t run_fused_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
+hipError_t run_fused_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
+// shapes the fused kernel (ctc_fused.hip) is instantiated for: logits input, V in {256, 512, 1024}, U <= 256
+inline bool fused_eligible(const Problem &p, const Layout &L) {
+  return p.wrt == 0 && (p.V == 256 || p.V == 512 || p.V == 1024) && L.NL <= 4 && p.B > 0 && p.T > 0;
+}
+inline hipError_t run_fused(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
+  return p.kind == 0 ? run_fused_classic(p, L, ws, loss, d_loss, grad, st) : run_fused_simplified(p, L, ws, loss, d_loss, grad, st);
+}
 size_t hessian_extra_bytes(int kind, int B, int T, int V, int U);
 hipError_t run_hessian(const Problem &p, const Layout &L, char *ws, const float *grad, float *hess, hipStream_t st);
 }  // namespace ctc
@@ -84,6 +94,15 @@ int ctc_amd_loss_grad(int kind, int wrt, const float *logits, const int32_t *lab
   if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
   ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // pipeline selection: the fused kernel (ctc_fused.hip) when the shape is eligible, else emit -> scan -> grad.
+  // CTC_AMD_PIPELINE=v1 forces the three-kernel pipeline (parity tests run both).
+  const char *pipe = getenv("CTC_AMD_PIPELINE");
+  const bool force_v1 = pipe && pipe[0] == 'v' && pipe[1] == '1';
+  if (grad && !force_v1 && ctc::fused_eligible(p, L)) {
+    hipError_t ef = ctc::run_fused(p, L, static_cast<char *>(workspace), loss, d_loss, grad, st);
+    if (ef != hipSuccess) return hip_fail(ef, "fused launch");
+    return CTC_AMD_OK;
+  }
   hipError_t e = ctc::run_emit_scan(p, L, static_cast<char *>(workspace), loss, grad ? 2 : 1, st);
   if (e != hipSuccess) return hip_fail(e, "emit/scan launch");
   if (grad) {
