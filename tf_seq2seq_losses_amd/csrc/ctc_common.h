@@ -25,9 +25,7 @@ __device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x
 
 // base-2 log(2^a + 2^b); operands are finite (sentinel instead of -inf).
 __device__ __forceinline__ float lse2(float a, float b) {
-  float m = fmaxf(a, b);
-  float d = fminf(a, b) - m;
-  return m + flog2(1.0f + fexp2(d));
+  return fmaxf(a, b) + flog2(1.0f + fexp2(-fabsf(a - b)));  // |.| and the negation are free source modifiers
 }
 
 // lane i receives x from lane i-1; lane 0 receives `fill` (DPP wave_shr:1, one VALU op, no LDS).
@@ -66,11 +64,12 @@ struct Problem {
 //                            [UP+1] = row max mx, [UP+2] = log2 sum_k exp(x_k - mx)  (both 0 for WRT_LOGPROBS)
 //   alpha [B][T+1][SRS]    : classic: pairs (closed, open) of label position l = i+1 at [2i, 2i+1], the l = 0 pair at
 //   beta                     [2UP, 2UP+1], offset (hi, lo) at [2UP+2, 2UP+3];  simplified: state l = i+1 at [i], l = 0 at
-//                            [UP], offset at [UP+2, UP+3]
+//                            [UP], offset at [UP+2, UP+3].  A second 16-byte tail [.. +4, +8) carries, in the fused kernel,
+//                            the softmax statistics (row max, log2 sum exp) of the frame the reader will process
 //   logp  [B] double       : log2 P(label | logits), -inf when infeasible
 struct Layout {
   int NL, UP, ERS, SRS;
-  size_t off_emis, off_alpha, off_beta, off_logp, off_extra, total;
+  size_t off_emis, off_alpha, off_beta, off_logp, off_dummy, off_extra, total;
 };
 
 inline int nl_for(int U) {
@@ -84,13 +83,14 @@ inline Layout make_layout(int kind, int B, int T, int U, size_t extra_bytes) {
   L.NL = nl_for(U);
   L.UP = L.NL * WAVE;
   L.ERS = L.UP + 4;
-  L.SRS = (kind == 0 ? 2 * L.UP : L.UP) + 4;
+  L.SRS = (kind == 0 ? 2 * L.UP : L.UP) + 8;
   auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
   size_t o = 0;
   L.off_emis = o;  o = al(o + (size_t)B * T * L.ERS * 4);
   L.off_alpha = o; o = al(o + (size_t)B * (T + 1) * L.SRS * 4);
   L.off_beta = o;  o = al(o + (size_t)B * (T + 1) * L.SRS * 4);
   L.off_logp = o;  o = al(o + (size_t)B * 8);
+  L.off_dummy = o; o = al(o + (size_t)B * 2 * 1024);  // per-wavefront sink for the pacing stores of the fused kernel
   L.off_extra = o; o = al(o + extra_bytes);
   L.total = o;
   return L;

@@ -22,30 +22,33 @@ namespace ctc {
 
 namespace fused {
 
-constexpr int PF = 16;  // frames of look-ahead (= unrolled block length = renormalisation period)
+constexpr int PF = 16;   // logits rows of look-ahead (= unrolled block length = renormalisation period)
+constexpr int PFS = 8;   // spilled lattice rows of look-ahead in phase 2 (keeps the kernel inside 256 VGPRs)
+constexpr int NPACE = 48; // pacing stores after a ring prologue (see Side::pace)
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // ---- wave64 reductions with DPP (result broadcast through an SGPR) ----
-#define CTC_DPP(old, src, ctrl, rmask, bctrl) \
-  __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), (ctrl), (rmask), 0xf, (bctrl)))
+// Hand-written: hipcc lowers __builtin_amdgcn_update_dpp reductions to mov + mov_dpp + op per level (18 instructions
+// per reduction); here every level is ONE DPP-fused VALU op.  Lanes without a valid DPP source are disabled and keep
+// their value.  `s_nop 1` = the 2 wait states a DPP read of a VGPR written by the previous VALU op needs (hipcc pads
+// nothing inside asm).  After the row_shr scan lane 15 of each 16-lane row holds the row result; row_bcast:15 / :31
+// carry it into lane 63.
+#define CTC_WAVE_REDUCE_ASM(OP)                                                      \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"            \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"            \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"            \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"            \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"         \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"         \
+  "s_nop 0"
 
 __device__ __forceinline__ float wave_sum_dpp(float v) {
-  v += CTC_DPP(0.f, v, 0x111, 0xf, true);   // row_shr:1
-  v += CTC_DPP(0.f, v, 0x112, 0xf, true);   // row_shr:2
-  v += CTC_DPP(0.f, v, 0x114, 0xf, true);   // row_shr:4
-  v += CTC_DPP(0.f, v, 0x118, 0xf, true);   // row_shr:8   -> lane 15 of each row holds the row sum
-  v += CTC_DPP(0.f, v, 0x142, 0xa, false);  // row_bcast:15 into rows 1,3
-  v += CTC_DPP(0.f, v, 0x143, 0xc, false);  // row_bcast:31 into rows 2,3 -> lane 63 holds the total
+  asm(CTC_WAVE_REDUCE_ASM("v_add_f32_dpp") : "+v"(v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max_dpp(float v) {
-  v = fmaxf(v, CTC_DPP(v, v, 0x111, 0xf, false));
-  v = fmaxf(v, CTC_DPP(v, v, 0x112, 0xf, false));
-  v = fmaxf(v, CTC_DPP(v, v, 0x114, 0xf, false));
-  v = fmaxf(v, CTC_DPP(v, v, 0x118, 0xf, false));
-  v = fmaxf(v, CTC_DPP(v, v, 0x142, 0xa, false));
-  v = fmaxf(v, CTC_DPP(v, v, 0x143, 0xc, false));
+  asm(CTC_WAVE_REDUCE_ASM("v_max_f32_dpp") : "+v"(v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float readlane_f(float v, int l) {
@@ -58,6 +61,7 @@ struct SRow {
   float a[NL];   // classic: closed part / simplified: the state
   float b[NL];   // classic: open part (unused for simplified)
   float4 tail;   // (state outside the slot range, -, off_hi, off_lo)
+  float2 stat;   // (row max, log2 sum exp) of the frame the reader processes with this row
 };
 
 template <int KIND, int NL>
@@ -75,6 +79,7 @@ __device__ __forceinline__ void load_srow(SRow<KIND, NL> &r, const float *__rest
       }
     }
     r.tail = *reinterpret_cast<const float4 *>(row + 2 * UP);
+    r.stat = *reinterpret_cast<const float2 *>(row + 2 * UP + 4);
   } else {
     const float *p = row + lane * NL;
     if constexpr (NL == 1) {
@@ -90,12 +95,13 @@ __device__ __forceinline__ void load_srow(SRow<KIND, NL> &r, const float *__rest
       }
     }
     r.tail = *reinterpret_cast<const float4 *>(row + UP);
+    r.stat = *reinterpret_cast<const float2 *>(row + UP + 4);
   }
 }
 
 template <int KIND, int NL>
 __device__ __forceinline__ void store_srow(float *__restrict__ row, int lane, int UP, const float (&a)[NL],
-                                           const float (&b)[NL], float4 tail) {
+                                           const float (&b)[NL], float4 tail, float2 stat) {
   if constexpr (KIND == 0) {
     float *p = row + 2 * lane * NL;
     if constexpr (NL == 1) {
@@ -105,7 +111,10 @@ __device__ __forceinline__ void store_srow(float *__restrict__ row, int lane, in
       for (int q = 0; q < NL / 2; ++q)
         *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(a[2 * q], b[2 * q], a[2 * q + 1], b[2 * q + 1]);
     }
-    *reinterpret_cast<float4 *>(row + 2 * UP) = tail;  // wave-uniform data, same address from every lane
+    // 32-byte wave-uniform tail in ONE store instruction: even lanes write the first half, odd lanes the second
+    const bool odd = lane & 1;
+    *reinterpret_cast<float4 *>(row + 2 * UP + (odd ? 4 : 0)) =
+        make_float4(odd ? stat.x : tail.x, odd ? stat.y : tail.y, odd ? 0.f : tail.z, odd ? 0.f : tail.w);
   } else {
     float *p = row + lane * NL;
     if constexpr (NL == 1) {
@@ -117,7 +126,9 @@ __device__ __forceinline__ void store_srow(float *__restrict__ row, int lane, in
       for (int q = 0; q < NL / 4; ++q)
         *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
     }
-    *reinterpret_cast<float4 *>(row + UP) = tail;
+    const bool odd = lane & 1;
+    *reinterpret_cast<float4 *>(row + UP + (odd ? 4 : 0)) =
+        make_float4(odd ? stat.x : tail.x, odd ? stat.y : tail.y, odd ? 0.f : tail.z, odd ? 0.f : tail.w);
   }
 }
 
@@ -152,11 +163,21 @@ struct Side {
   float *own_rows;      // spill rows this side writes
   const float *oth_rows;  // spill rows the other side writes
   int SRS;
+  float *sink;  // global: 1 KB per wavefront, target of the pacing stores of the ring prologues
   float *xs;    // LDS: 2 x (V + 4) floats, gather copies of the logits row
   float *bins;  // LDS: V floats, posterior per token
   float dl;
 
   __device__ __forceinline__ int frame(int t0, int k) const { return DIR == 0 ? t0 + k : t0 - k; }
+
+  // Pacing store.  hipcc derives the s_waitcnt vmcnt(N) of a software-pipelined loop from the LEAST number of memory
+  // operations it can prove to lie between a prefetch and its use, and that minimum comes from the ring prologue where
+  // the prefetches would be back to back.  Giving every prologue slot as many memory operations as a steady-state step
+  // has makes the derived N as large as in the steady state, so a wait never reaches stores/loads of the last few steps.
+  __device__ __forceinline__ void pace(int slot) const {
+    volatile float *q = sink + lane * 4;  // volatile: identical stores to one address must not be merged away
+    q[0] = (float)slot;
+  }
 
   __device__ __forceinline__ void load_x(float4 (&xr)[VPL], int t) const {
     const float *row = xbase + (long)t * V + lane * 4;
@@ -164,9 +185,9 @@ struct Side {
     for (int q = 0; q < VPL; ++q) xr[q] = *reinterpret_cast<const float4 *>(row + 256 * q);
   }
 
-  // log-softmax statistics + emission gather (tools.py:27-40, base_loss.py:328-344, 365-371)
-  __device__ __forceinline__ void emit(const float4 (&xr)[VPL], int parity, Emis<NL> &e) const {
-    float mx = 0.f, l2s = 0.f;
+  // log-softmax statistics (tools.py:27-40): row max and log2 sum exp by DPP reductions
+  __device__ __forceinline__ void stats(const float4 (&xr)[VPL], float &mx, float &l2s) const {
+    mx = 0.f; l2s = 0.f;
     if constexpr (LOGITS) {
       float m = fmaxf(fmaxf(xr[0].x, xr[0].y), fmaxf(xr[0].z, xr[0].w));
 #pragma unroll
@@ -180,23 +201,38 @@ struct Side {
              fexp2((xr[q].w - mx) * LOG2E);
       l2s = flog2(wave_sum_dpp(s));
     }
+  }
+
+  // emission gather through an LDS copy of the row (base_loss.py:328-344, 365-371), split in two so that the LDS
+  // round trip of frame t+1 is in flight while frame t is processed: gather_issue early, gather_finish late.
+  struct Raw { float xg[NL]; float xb; };
+  __device__ __forceinline__ void gather_issue(const float4 (&xr)[VPL], int parity, Raw &w) const {
     float *buf = xs + parity * (V + 4);
 #pragma unroll
     for (int q = 0; q < VPL; ++q) *reinterpret_cast<float4 *>(buf + 256 * q + lane * 4) = xr[q];
-    __builtin_amdgcn_wave_barrier();
     const char *bb = reinterpret_cast<const char *>(buf);
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      float xg = *reinterpret_cast<const float *>(bb + tokoff[j]);
-      float y = (xg - mx) * LOG2E - l2s;
-      e.y[j] = (y > NEG) ? y : NEG;  // also turns NaN (-inf - -inf) into the sentinel
-    }
-    float xb = buf[blank];
-    float bl = (xb - mx) * LOG2E - l2s;
-    e.bl = (bl > NEG) ? bl : NEG;
+    for (int j = 0; j < NL; ++j) w.xg[j] = *reinterpret_cast<const float *>(bb + tokoff[j]);
+    w.xb = buf[blank];
+  }
+  __device__ __forceinline__ void gather_finish(const Raw &w, float mx, float l2s, Emis<NL> &e) const {
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
+      e.y[j] = fmaxf((w.xg[j] - mx) * LOG2E - l2s, NEG);  // v_max returns the non-NaN operand: (-inf) - (-inf) -> sentinel
+    e.bl = fmaxf((w.xb - mx) * LOG2E - l2s, NEG);
     e.mx = mx;
     e.l2s = l2s;
-    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ void gather(const float4 (&xr)[VPL], int parity, float mx, float l2s, Emis<NL> &e) const {
+    Raw w;
+    gather_issue(xr, parity, w);
+    gather_finish(w, mx, l2s, e);
+  }
+
+  __device__ __forceinline__ void emit(const float4 (&xr)[VPL], int parity, Emis<NL> &e) const {
+    float mx, l2s;
+    stats(xr, mx, l2s);
+    gather(xr, parity, mx, l2s, e);
   }
 
   // one lattice step (identical recursions to Scan::step in ctc_kernels.hip)
@@ -272,7 +308,7 @@ struct Side {
   }
 
   // spill the current state as lattice row `t` in the layout the other side is aligned with
-  __device__ __forceinline__ void spill(int t) const {
+  __device__ __forceinline__ void spill(int t, float smx, float sl2s) const {
     float cs[NL];
     float tx;
     if constexpr (DIR == 0) {  // slot i <- state_c(l=i): previous slot's c; tail <- state_c(l=UP): last slot's c
@@ -287,7 +323,8 @@ struct Side {
       tx = readlane_f(c[0], 0);
     }
     const float oh = (float)off;
-    store_srow<KIND, NL>(own_rows + (long)t * SRS, lane, UP, cs, o, make_float4(tx, 0.f, oh, (float)(off - (double)oh)));
+    store_srow<KIND, NL>(own_rows + (long)t * SRS, lane, UP, cs, o, make_float4(tx, 0.f, oh, (float)(off - (double)oh)),
+                         make_float2(smx, sl2s));
   }
 
   // log2 P at the meeting point from this side's state and the other side's row of the same time index
@@ -315,19 +352,19 @@ struct Side {
                                            const float4 (&xr)[VPL], const Emis<NL> &e) const {
 #pragma unroll
     for (int q = 0; q < VPL; ++q) *reinterpret_cast<float4 *>(bins + 256 * q + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    float qb = (lane == 0) ? fminf(fexp2(s0), 1.f) : 0.f;
+    float qb = (lane == 0) ? fexp2(s0) : 0.f;
     float qt[NL];
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      qb += fminf(fexp2(s1[j]), 1.f);
-      qt[j] = fminf(fexp2(s2[j]), 1.f);
+      qb += fexp2(s1[j]);
+      qt[j] = fexp2(s2[j]);
     }
-    __builtin_amdgcn_wave_barrier();
+    // (no wave barrier needed: LDS ops of one wave execute in order and may-alias accesses keep program order)
     char *bb = reinterpret_cast<char *>(bins);
 #pragma unroll
     for (int j = 0; j < NL; ++j) atomicAdd(reinterpret_cast<float *>(bb + tokoff[j]), qt[j]);  // pad slot absorbs i >= ll
     qb = wave_sum_dpp(qb);
-    __builtin_amdgcn_wave_barrier();
+    // (no wave barrier needed: LDS ops of one wave execute in order and may-alias accesses keep program order)
     float *g = gbase + (long)t * V + lane * 4;
 #pragma unroll
     for (int q = 0; q < VPL; ++q) {
@@ -344,30 +381,23 @@ struct Side {
       }
       *reinterpret_cast<float4 *>(g + 256 * q) = r;
     }
-    __builtin_amdgcn_wave_barrier();
+    // (no wave barrier needed: LDS ops of one wave execute in order and may-alias accesses keep program order)
   }
 
-  // phase-2 frame: posterior of frame t from this side's state and the other side's row, then the gradient row
-  __device__ __forceinline__ void frame2(int t, const float4 (&xr)[VPL], int parity, const SRow<KIND, NL> &r, double dlogp) {
-    Emis<NL> e;
-    emit(xr, parity, e);
+  // phase-2 frame: posterior of frame t from this side's state and the other side's row, then the gradient row.
+  //   classic    A: after the step, state = alpha[t+1], r = beta[t+1]      B: before the step, state = beta[t+1], r = alpha[t+1]
+  //   simplified A: before the step, state = a[t], r = b[t+1]              B: before the step, state = b[t+1], r = a[t]
+  // (blank part, token part) per slot:  classic (c + r.a, o + r.b);  simplified A (c + bl + r.a, pin + y + r.a);
+  // simplified B (c + bl + r.a, r.a + y + next)   -- regroupings of classic_ctc_loss.py:565-669 / simplified_ctc_loss.py:456-534
+  __device__ __forceinline__ void frame2(int t, const float4 (&xr)[VPL], const Emis<NL> &e, const SRow<KIND, NL> &r, double dlogp) {
     float s1[NL], s2[NL], s0;
-    if constexpr (KIND == 0 && DIR == 0) {
-      step(e);  // state = alpha[t+1]; r = beta[t+1]
-      const float sc = (float)(off + (double)r.tail.z + (double)r.tail.w - dlogp);
+    if constexpr (KIND == 0 && DIR == 0) step(e);
+    const float sc = (float)((double)r.tail.z + (off - dlogp)) + r.tail.w;
+    if constexpr (KIND == 0) {
 #pragma unroll
       for (int j = 0; j < NL; ++j) { s1[j] = c[j] + r.a[j] + sc; s2[j] = o[j] + r.b[j] + sc; }
       s0 = cx + r.tail.x + sc;
-      grad_row(t, s1, s2, s0, xr, e);
-    } else if constexpr (KIND == 0 && DIR == 1) {
-      const float sc = (float)(off + (double)r.tail.z + (double)r.tail.w - dlogp);  // state = beta[t+1]; r = alpha[t+1]
-#pragma unroll
-      for (int j = 0; j < NL; ++j) { s1[j] = c[j] + r.a[j] + sc; s2[j] = o[j] + r.b[j] + sc; }
-      s0 = cx + r.tail.x + sc;
-      grad_row(t, s1, s2, s0, xr, e);
-      step(e);
-    } else if constexpr (KIND == 1 && DIR == 0) {
-      const float sc = (float)(off + (double)r.tail.z + (double)r.tail.w - dlogp);  // state = a[t]; r = b[t+1]
+    } else if constexpr (DIR == 0) {
       float pin0 = from_prev_lane(c[NL - 1], cx);
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
@@ -376,10 +406,7 @@ struct Side {
         s2[j] = pin + e.y[j] + r.a[j] + sc;
       }
       s0 = cx + e.bl + r.tail.x + sc;
-      grad_row(t, s1, s2, s0, xr, e);
-      step(e);
     } else {
-      const float sc = (float)(off + (double)r.tail.z + (double)r.tail.w - dlogp);  // state = b[t+1]; r = a[t]
       float nin = from_next_lane(c[0], cx);
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
@@ -388,9 +415,9 @@ struct Side {
         s2[j] = r.a[j] + e.y[j] + nx + sc;
       }
       s0 = cx + e.bl + r.tail.x + sc;
-      grad_row(t, s1, s2, s0, xr, e);
-      step(e);
     }
+    grad_row(t, s1, s2, s0, xr, e);
+    if constexpr (!(KIND == 0 && DIR == 0)) step(e);
   }
 
   __device__ __forceinline__ void zero_rows(int t_from, int t_to) const {
@@ -406,7 +433,8 @@ template <int KIND, int NL, int VPL, int DIR, bool LOGITS>
 __device__ __forceinline__ void run_side(const Problem &p, const Layout &L, float *__restrict__ alpha_ws,
                                          float *__restrict__ beta_ws, double *__restrict__ logp_ws,
                                          float *__restrict__ loss, const float *__restrict__ d_loss,
-                                         float *__restrict__ grad, float *lds_x, float *lds_bins) {
+                                         float *__restrict__ grad, float *__restrict__ sink_ws, float *lds_x,
+                                         float *lds_bins) {
   constexpr int V = 256 * VPL;
   using S_t = Side<KIND, NL, VPL, DIR, LOGITS>;
   S_t S;
@@ -423,6 +451,7 @@ __device__ __forceinline__ void run_side(const Problem &p, const Layout &L, floa
   S.gbase = grad + (long)b * T * V;
   S.own_rows = (DIR == 0 ? alpha_ws : beta_ws) + (long)b * (T + 1) * L.SRS;
   S.oth_rows = (DIR == 0 ? beta_ws : alpha_ws) + (long)b * (T + 1) * L.SRS;
+  S.sink = sink_ws + ((long)b * 2 + DIR) * 256;
   S.xs = lds_x;
   S.bins = lds_bins;
   S.dl = d_loss ? d_loss[b] : 1.0f;
@@ -465,41 +494,74 @@ __device__ __forceinline__ void run_side(const Problem &p, const Layout &L, floa
       if (KIND == 0 && i == ll - 1) S.o[j] = 0.f;
     }
   }
-  S.spill(DIR == 0 ? 0 : len);
+  // Which frame's softmax statistics travel with a spilled row: the frame at which the OTHER side reads that row.
+  // Classic A: row t+1 (written after frame t) is read by B at frame t = the current frame; in the three other cases
+  // it is the next frame in this side's own order, whose emissions are computed one step ahead (skewed pipeline).
+  constexpr bool STAT_CUR = (KIND == 0 && DIR == 0);
 
   // ================= phase 1 =================
   // A: frames 0 .. tm-1 (row t+1 after frame t);  B: frames len-1 .. tm (row t after frame t)
   {
     const int n1 = (DIR == 0) ? tm : len - tm;
     const int t0 = (DIR == 0) ? 0 : len - 1;
-    auto fr = [&](int k) -> int { int kk = k < n1 ? k : n1 - 1; return DIR == 0 ? t0 + kk : t0 - kk; };
+    auto fr = [&](int k) -> int {
+      int kk = k < n1 ? k : n1 - 1;
+      kk = kk < 0 ? 0 : kk;
+      int t = DIR == 0 ? t0 + kk : t0 - kk;
+      return t < 0 ? 0 : t;
+    };
+    Emis<NL> ecur;
+    ecur.mx = 0.f; ecur.l2s = 0.f; ecur.bl = NEG;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) ecur.y[j] = NEG;
     if (n1 > 0) {
       float4 xb[PF][VPL];
 #pragma unroll
-      for (int d = 0; d < PF; ++d) S.load_x(xb[d], fr(d));
+      for (int d = 0; d < PF / 2; ++d) S.load_x(xb[d], fr(d));  // first half; the second half is loaded at step 0
+#pragma unroll
+      for (int d = PF / 2; d < PF; ++d) xb[d][0] = xb[0][0];     // (defined values for the compiler; overwritten at step 0)
+      S.emit(xb[0], 0, ecur);
+      S.spill(DIR == 0 ? 0 : len, ecur.mx, ecur.l2s);  // initial row; read by the other side at this side's first frame
       int k0 = 0;
       for (; k0 + PF <= n1; k0 += PF) {
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
-          Emis<NL> e;
-          S.emit(xb[d], d & 1, e);
-          S.load_x(xb[d], fr(k0 + d + PF));
-          S.step(e);
+          typename S_t::Raw w;
+          S.gather_issue(xb[(d + 1) % PF], (d + 1) & 1, w);  // LDS round trip of the next frame starts now
+          float nmx, nl2s;
+          S.stats(xb[(d + 1) % PF], nmx, nl2s);                // ... and its softmax statistics: independent of the lattice
+          S.step(ecur);
+          // Ring refill in two batches per block (hipcc sizes a vmcnt wait by the memory operations between a load and
+          // the loop's back edge: loads issued early in the body get large counts).  Slots 8..15 (this block's second
+          // half) are refilled at step 0... no: see the prologue -- at step 0 the NEXT block's slots are not free yet.
+          if (d == PF / 2) {
+#pragma unroll
+            for (int q = 0; q < PF / 2; ++q) S.load_x(xb[q], fr(k0 + PF + q));            // frames of the next block, first half
+          }
+          if (d == 0) {
+#pragma unroll
+            for (int q = PF / 2; q < PF; ++q) S.load_x(xb[q], fr(k0 + q));                 // this block, second half
+          }
           if (d == PF - 1) S.renorm();
           const int t = fr(k0 + d);
-          S.spill(DIR == 0 ? t + 1 : t);
+          S.spill(DIR == 0 ? t + 1 : t, STAT_CUR ? ecur.mx : nmx, STAT_CUR ? ecur.l2s : nl2s);
+          S.gather_finish(w, nmx, nl2s, ecur);
+          __builtin_amdgcn_sched_barrier(0);  // keep every step's loads/stores in program order (vmcnt counts stay large)
         }
       }
       // tail (< PF frames): rolled loop with direct loads -- one copy of the step body, runs at most once per phase
       for (int k = k0; k < n1; ++k) {
         const int t = fr(k);
         float4 xr[VPL];
-        S.load_x(xr, t);
-        Emis<NL> e;
-        S.emit(xr, k & 1, e);
-        S.step(e);
-        S.spill(DIR == 0 ? t + 1 : t);
+        S.load_x(xr, fr(k + 1));
+        Emis<NL> enext;
+        S.emit(xr, (k + 1) & 1, enext);
+        S.step(ecur);
+        S.spill(DIR == 0 ? t + 1 : t, STAT_CUR ? ecur.mx : enext.mx, STAT_CUR ? ecur.l2s : enext.l2s);
+        ecur = enext;
       }
+    } else {
+      S.spill(DIR == 0 ? 0 : len, 0.f, 0.f);
     }
   }
 
@@ -518,7 +580,8 @@ __device__ __forceinline__ void run_side(const Problem &p, const Layout &L, floa
   }
 
   // ================= phase 2 =================
-  // A: frames tm .. len-1, needs beta[t+1];  B: frames tm-1 .. 0, needs alpha[t+1] (classic) / a[t] (simplified)
+  // A: frames tm .. len-1, needs beta[t+1];  B: frames tm-1 .. 0, needs alpha[t+1] (classic) / a[t] (simplified).
+  // The softmax statistics of every frame come with the other side's row: no reductions on this pass.
   const int n2 = (DIR == 0) ? len - tm : tm;
   const int t0 = (DIR == 0) ? tm : tm - 1;
   if (dlogp == -INFINITY) {
@@ -534,20 +597,43 @@ __device__ __forceinline__ void run_side(const Problem &p, const Layout &L, floa
       return S.oth_rows + (long)idx * L.SRS;
     };
     float4 xb[PF][VPL];
-    SRow<KIND, NL> rb[PF];
+    SRow<KIND, NL> rb[PFS];
 #pragma unroll
-    for (int d = 0; d < PF; ++d) {
-      S.load_x(xb[d], fr(d));
-      load_srow<KIND, NL>(rb[d], orow(fr(d)), lane, UP);
-    }
+    for (int d = 0; d < PF / 2; ++d) S.load_x(xb[d], fr(d));
+#pragma unroll
+    for (int d = PF / 2; d < PF; ++d) xb[d][0] = xb[0][0];
+#pragma unroll
+    for (int d = 0; d < PFS / 2; ++d) load_srow<KIND, NL>(rb[d], orow(fr(d)), lane, UP);
+#pragma unroll
+    for (int d = PFS / 2; d < PFS; ++d) rb[d] = rb[0];
+    Emis<NL> ecur;
+    S.gather(xb[0], 0, rb[0].stat.x, rb[0].stat.y, ecur);
     int k0 = 0;
     for (; k0 + PF <= n2; k0 += PF) {
 #pragma unroll
       for (int d = 0; d < PF; ++d) {
-        S.frame2(fr(k0 + d), xb[d], d & 1, rb[d], dlogp);
-        S.load_x(xb[d], fr(k0 + d + PF));
-        load_srow<KIND, NL>(rb[d], orow(fr(k0 + d + PF)), lane, UP);
+        typename S_t::Raw w;
+        S.gather_issue(xb[(d + 1) % PF], (d + 1) & 1, w);
+        const float nmx = rb[(d + 1) % PFS].stat.x, nl2s = rb[(d + 1) % PFS].stat.y;
+        S.frame2(fr(k0 + d), xb[d], ecur, rb[d % PFS], dlogp);
+        if (d == PF / 2) {
+#pragma unroll
+          for (int q = 0; q < PF / 2; ++q) S.load_x(xb[q], fr(k0 + PF + q));
+        }
+        if (d == 0) {
+#pragma unroll
+          for (int q = PF / 2; q < PF; ++q) S.load_x(xb[q], fr(k0 + q));
+        }
+        if (d % (PFS / 2) == 0) {  // lattice rows: ring of PFS, refilled in batches of PFS/2, PFS/2 .. PFS frames ahead
+#pragma unroll
+          for (int q = 0; q < PFS / 2; ++q) {
+            const int slot = (d + PFS / 2 + q) % PFS;
+            load_srow<KIND, NL>(rb[slot], orow(fr(k0 + d + PFS / 2 + q)), lane, UP);
+          }
+        }
         if (d == PF - 1) S.renorm();
+        S.gather_finish(w, nmx, nl2s, ecur);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     for (int k = k0; k < n2; ++k) {
@@ -556,7 +642,8 @@ __device__ __forceinline__ void run_side(const Problem &p, const Layout &L, floa
       SRow<KIND, NL> r;
       S.load_x(xr, t);
       load_srow<KIND, NL>(r, orow(t), lane, UP);
-      S.frame2(t, xr, k & 1, r, dlogp);
+      S.gather(xr, k & 1, r.stat.x, r.stat.y, ecur);
+      S.frame2(t, xr, ecur, r, dlogp);
     }
   }
 }
@@ -565,15 +652,15 @@ template <int KIND, int NL, int VPL, bool LOGITS>
 __global__ __launch_bounds__(128) void fused_kernel(Problem p, Layout L, float *__restrict__ alpha_ws,
                                                      float *__restrict__ beta_ws, double *__restrict__ logp_ws,
                                                      float *__restrict__ loss, const float *__restrict__ d_loss,
-                                                     float *__restrict__ grad) {
+                                                     float *__restrict__ grad, float *__restrict__ sink_ws) {
   constexpr int V = 256 * VPL;
   __shared__ __attribute__((aligned(16))) float lds_x[2][2 * (V + 4)];
   __shared__ __attribute__((aligned(16))) float lds_bins[2][V + 4];
   const int w = threadIdx.x >> 6;
   if (w == 0)
-    run_side<KIND, NL, VPL, 0, LOGITS>(p, L, alpha_ws, beta_ws, logp_ws, loss, d_loss, grad, lds_x[0], lds_bins[0]);
+    run_side<KIND, NL, VPL, 0, LOGITS>(p, L, alpha_ws, beta_ws, logp_ws, loss, d_loss, grad, sink_ws, lds_x[0], lds_bins[0]);
   else
-    run_side<KIND, NL, VPL, 1, LOGITS>(p, L, alpha_ws, beta_ws, logp_ws, loss, d_loss, grad, lds_x[1], lds_bins[1]);
+    run_side<KIND, NL, VPL, 1, LOGITS>(p, L, alpha_ws, beta_ws, logp_ws, loss, d_loss, grad, sink_ws, lds_x[1], lds_bins[1]);
 }
 
 }  // namespace fused
@@ -585,18 +672,18 @@ __global__ __launch_bounds__(128) void fused_kernel(Problem p, Layout L, float *
 
 template <int NL, int VPL>
 static void launch_v(const Problem &p, const Layout &L, float *a, float *b, double *lp, float *loss, const float *d_loss,
-                     float *grad, hipStream_t st) {
+                     float *grad, float *sink, hipStream_t st) {
   hipLaunchKernelGGL((fused::fused_kernel<CTC_FUSED_KIND, NL, VPL, true>), dim3(p.B), dim3(128), 0, st, p, L, a, b, lp,
-                     loss, d_loss, grad);
+                     loss, d_loss, grad, sink);
 }
 
 template <int NL>
 static hipError_t launch_nl(const Problem &p, const Layout &L, float *a, float *b, double *lp, float *loss,
-                            const float *d_loss, float *grad, hipStream_t st) {
+                            const float *d_loss, float *grad, float *sink, hipStream_t st) {
   switch (p.V / 256) {
-    case 1: launch_v<NL, 1>(p, L, a, b, lp, loss, d_loss, grad, st); break;
-    case 2: launch_v<NL, 2>(p, L, a, b, lp, loss, d_loss, grad, st); break;
-    case 4: launch_v<NL, 4>(p, L, a, b, lp, loss, d_loss, grad, st); break;
+    case 1: launch_v<NL, 1>(p, L, a, b, lp, loss, d_loss, grad, sink, st); break;
+    case 2: launch_v<NL, 2>(p, L, a, b, lp, loss, d_loss, grad, sink, st); break;
+    case 4: launch_v<NL, 4>(p, L, a, b, lp, loss, d_loss, grad, sink, st); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -611,10 +698,11 @@ hipError_t run_fused_simplified
   float *alpha = reinterpret_cast<float *>(ws + L.off_alpha);
   float *beta = reinterpret_cast<float *>(ws + L.off_beta);
   double *logp = reinterpret_cast<double *>(ws + L.off_logp);
+  float *sink = reinterpret_cast<float *>(ws + L.off_dummy);
   switch (L.NL) {
-    case 1: return launch_nl<1>(p, L, alpha, beta, logp, loss, d_loss, grad, st);
-    case 2: return launch_nl<2>(p, L, alpha, beta, logp, loss, d_loss, grad, st);
-    case 4: return launch_nl<4>(p, L, alpha, beta, logp, loss, d_loss, grad, st);
+    case 1: return launch_nl<1>(p, L, alpha, beta, logp, loss, d_loss, grad, sink, st);
+    case 2: return launch_nl<2>(p, L, alpha, beta, logp, loss, d_loss, grad, sink, st);
+    case 4: return launch_nl<4>(p, L, alpha, beta, logp, loss, d_loss, grad, sink, st);
     default: return hipErrorInvalidValue;
   }
 }
