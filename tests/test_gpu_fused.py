@@ -1,4 +1,4 @@
-"""The fused loss+gradient kernel (csrc/ctc_fused.hip; V in {256, 512, 1024}, logits input) against the float64
+"""The fused loss+gradient kernels (csrc/ctc_fused4.hip, csrc/ctc_fused.hip; V in {256, 512, 1024}, logits input) against the float64
 C oracle and against the three-kernel pipeline (CTC_AMD_PIPELINE=v1), including the edge cases the reference tests:
 ragged and zero lengths, infeasible samples, empty labels, repeated tokens, d_loss weighting."""
 import os
@@ -33,13 +33,14 @@ def _run(kind, logits, labels, ll, tl, pipeline, d_loss=None):
 
 
 def _check(kind, logits, labels, ll, tl, d_loss=None):
-    lf, gf = _run(kind, logits, labels, ll, tl, "fused", d_loss)
+    lf, gf = _run(kind, logits, labels, ll, tl, "fused4", d_loss)
+    l2, g2 = _run(kind, logits, labels, ll, tl, "fused2", d_loss)
     l1, g1 = _run(kind, logits, labels, ll, tl, "v1", d_loss)
     rl, rg = C.loss_grad(kind, labels, logits, ll, tl, 0)
     if d_loss is not None:
         rg = rg * d_loss[:, None, None]
     fin = np.isfinite(rl)
-    for lo, gr, name in ((lf, gf, "fused"), (l1, g1, "v1")):
+    for lo, gr, name in ((lf, gf, "fused4"), (l2, g2, "fused2"), (l1, g1, "v1")):
         assert np.array_equal(np.isfinite(lo), fin), name
         assert np.all(lo[~fin] == np.inf), name
         if fin.any():
@@ -74,14 +75,15 @@ def test_fused_edge_lengths(kind):
     ll = np.array([0, 1, 1, 6, 0, 3, 6, 6, 2, 5], dtype=np.int32)   # sample 3: too long; sample 6: classic needs 11 frames
     d_loss = rng.standard_normal(B).astype(np.float32)
     tl_ref = np.minimum(tl, T)
-    lf, gf = _run(kind, logits, labels, ll, tl, "fused", d_loss)
     rl, rg = C.loss_grad(kind, labels, logits, ll, tl_ref, 0)
     rg = rg * d_loss[:, None, None]
     fin = np.isfinite(rl)
-    assert np.array_equal(np.isfinite(lf), fin)
-    assert (np.abs(lf[fin] - rl[fin]) / np.maximum(1, np.abs(rl[fin]))).max() < TOL
-    assert np.abs(gf - rg).max() < TOL
-    assert lf[0] == 0.0 and np.all(gf[0] == 0)  # T=0-like sample with empty label: loss 0
+    for pipeline in ("fused4", "fused2"):
+        lf, gf = _run(kind, logits, labels, ll, tl, pipeline, d_loss)
+        assert np.array_equal(np.isfinite(lf), fin), pipeline
+        assert (np.abs(lf[fin] - rl[fin]) / np.maximum(1, np.abs(rl[fin]))).max() < TOL, pipeline
+        assert np.abs(gf - rg).max() < TOL, pipeline
+        assert lf[0] == 0.0 and np.all(gf[0] == 0), pipeline  # T=0-like sample with empty label: loss 0
 
 
 @pytest.mark.parametrize("kind", ["classic", "simplified"])

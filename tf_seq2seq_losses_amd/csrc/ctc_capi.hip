@@ -12,7 +12,16 @@ hipError_t run_grad(const Problem &p, const Layout &L, char *ws, const float *d_
 hipError_t run_convert(const Problem &p, const Layout &L, char *ws, float *alpha_out, float *beta_out, hipStream_t st);
 hipError_t run_fused_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 hipError_t run_fused_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
-// shapes the fused kernel (ctc_fused.hip) is instantiated for: logits input, V in {256, 512, 1024}, U <= 256
+hipError_t run_fused4_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
+hipError_t run_fused4_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
+// shapes the chain + helper kernel (ctc_fused4.hip) is instantiated for: logits input, V = 256, U <= 128 (LDS budget)
+inline bool fused4_eligible(const Problem &p, const Layout &L) {
+  return p.wrt == 0 && p.V == 256 && L.NL <= 2 && p.B > 0 && p.T > 0;
+}
+inline hipError_t run_fused4(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
+  return p.kind == 0 ? run_fused4_classic(p, L, ws, loss, d_loss, grad, st) : run_fused4_simplified(p, L, ws, loss, d_loss, grad, st);
+}
+// shapes the two-wavefront fused kernel (ctc_fused.hip) is instantiated for: logits input, V in {256, 512, 1024}, U <= 256
 inline bool fused_eligible(const Problem &p, const Layout &L) {
   return p.wrt == 0 && (p.V == 256 || p.V == 512 || p.V == 1024) && L.NL <= 4 && p.B > 0 && p.T > 0;
 }
@@ -94,10 +103,17 @@ int ctc_amd_loss_grad(int kind, int wrt, const float *logits, const int32_t *lab
   if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
   ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // pipeline selection: the fused kernel (ctc_fused.hip) when the shape is eligible, else emit -> scan -> grad.
-  // CTC_AMD_PIPELINE=v1 forces the three-kernel pipeline (parity tests run both).
+  // pipeline selection: fused4 (ctc_fused4.hip: chain + helper wavefronts) > fused2 (ctc_fused.hip: two self-contained
+  // wavefronts) > v1 (emit -> scan -> grad), by shape eligibility.  CTC_AMD_PIPELINE=v1|fused2 forces a lower tier
+  // (the parity tests run all three).
   const char *pipe = getenv("CTC_AMD_PIPELINE");
   const bool force_v1 = pipe && pipe[0] == 'v' && pipe[1] == '1';
+  const bool force_f2 = pipe && pipe[0] == 'f' && pipe[5] == '2';
+  if (grad && !force_v1 && !force_f2 && ctc::fused4_eligible(p, L)) {
+    hipError_t ef = ctc::run_fused4(p, L, static_cast<char *>(workspace), loss, d_loss, grad, st);
+    if (ef != hipSuccess) return hip_fail(ef, "fused4 launch");
+    return CTC_AMD_OK;
+  }
   if (grad && !force_v1 && ctc::fused_eligible(p, L)) {
     hipError_t ef = ctc::run_fused(p, L, static_cast<char *>(workspace), loss, d_loss, grad, st);
     if (ef != hipSuccess) return hip_fail(ef, "fused launch");

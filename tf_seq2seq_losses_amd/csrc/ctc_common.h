@@ -90,7 +90,7 @@ inline Layout make_layout(int kind, int B, int T, int U, size_t extra_bytes) {
   L.off_alpha = o; o = al(o + (size_t)B * (T + 1) * L.SRS * 4);
   L.off_beta = o;  o = al(o + (size_t)B * (T + 1) * L.SRS * 4);
   L.off_logp = o;  o = al(o + (size_t)B * 8);
-  L.off_dummy = o; o = al(o + (size_t)B * 2 * 1024);  // per-wavefront sink for the pacing stores of the fused kernel
+  L.off_dummy = o; o = al(o + (size_t)B * 2 * 1024);  // (also: 16 B per wavefront of diagnostic stamps)  // per-wavefront sink for the pacing stores of the fused kernel
   L.off_extra = o; o = al(o + extra_bytes);
   L.total = o;
   return L;

@@ -1,0 +1,632 @@
+// Fused loss + gradient kernel for gfx950, pipeline v3: one workgroup of FOUR wavefronts per utterance, one per SIMD.
+//
+//   wave 0 / 1 : chain A / chain B -- nothing but the lattice recursion (alpha forward from frame 0, beta backward from
+//                frame len-1; meet in the middle like ctc_fused.hip), emissions read from LDS, posterior exponents
+//                written to LDS, lattice rows spilled (phase 1) / the other side's rows read (phase 2) from HBM.
+//   wave 2 / 3 : helper A / helper B -- everything that is not sequential: logits rows from HBM (prefetched one block
+//                ahead in registers), log-softmax statistics by DPP reductions, emission gather through an LDS copy of
+//                the row (E stage, one block AHEAD of its chain); posterior scatter with ds_add_f32 into an LDS token
+//                row and the softmax - posterior store (G stage, one block BEHIND its chain).
+//   Hand-off granularity is a block of BLK = 16 frames: E rows and S rows are double-buffered in LDS and all four waves
+//   meet at ONE s_barrier per block (raw s_barrier + lgkmcnt(0): a __syncthreads() would also drain the register
+//   prefetch rings).  All waves derive the same iteration counts from (len), so barrier counts match by construction.
+//
+//   iteration `it` of a phase:   helper: E(block it)      chain: block it-1      helper: G(block it-2)   [phase 2 only]
+//
+// References: classic_ctc_loss.py:310-462,565-669, simplified_ctc_loss.py:291-438,456-534, base_loss.py:262-298,328-344,
+// 420-468, tools.py:27-40.  Eligibility: V in {256,512,1024}, U <= 128 (LDS budget); otherwise ctc_fused.hip / v1 run.
+#include "ctc_fused_common.h"
+
+#ifndef CTC_FUSED_KIND
+#error "compile with -DCTC_FUSED_KIND=0 (classic) or 1 (simplified)"
+#endif
+
+namespace ctc {
+namespace fused4 {
+
+using namespace ctc::fused;
+
+constexpr int BLK = 16;
+
+__device__ __forceinline__ void block_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed; vmcnt untouched
+  __builtin_amdgcn_s_barrier();
+}
+
+#ifdef CTC_FUSED4_STAMPS
+// Diagnostic build only: per-wavefront cycles spent working vs. waiting at the block barrier, written to the sink area.
+struct Stamps {
+  unsigned long long work = 0, wait = 0, t0 = 0, work1 = 0;
+  __device__ __forceinline__ void begin() { t0 = __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void mid() { unsigned long long t = __builtin_amdgcn_s_memtime(); work += t - t0; t0 = t; }
+  __device__ __forceinline__ void end() { unsigned long long t = __builtin_amdgcn_s_memtime(); wait += t - t0; t0 = t; }
+  __device__ __forceinline__ void phase1_done() { work1 = work; }
+  __device__ __forceinline__ void dump(unsigned long long *dst, int lane) { if (lane == 0) { dst[0] = work; dst[1] = wait; dst[2] = work1; dst[3] = 0; } }
+};
+#define STAMP(x) x
+#else
+#define STAMP(x)
+#endif
+
+template <int KIND, int NL, int VPL, int NH>
+struct Lds {
+  static constexpr int V = 256 * VPL, UP = 64 * NL;
+  static constexpr int ES = UP + 4;       // E row: y[UP], bl, mx, l2s, -
+  static constexpr int RS = 2 * UP + 8;   // R/S row.  As R (written by a helper): the other side's lattice row exactly as it
+                                          // lies in HBM (Layout::SRS floats).  As S (written in place by the chain): (s1, s2)
+                                          // per slot, s0 at [2 UP].
+  float E[2][2][BLK][ES];                 // [side][block parity]
+  float R[2][3][BLK][RS];                 // [side][block % 3]: filled (helper) -> transformed (chain) -> consumed (helper)
+  float xcopy[2 * NH][V + 4];             // per helper: gather copy of a logits row
+  float bins[2 * NH][V + 4];              // per helper: posterior token row
+  float dump[2 + 2 * NH][64];             // per wavefront: sink of the branch-free single-lane LDS writes
+  int feasible;
+};
+
+// ------------------------------------------------------------------------------------------------
+// chain wavefront
+// ------------------------------------------------------------------------------------------------
+template <int KIND, int NL, int VPL, int NH, int DIR>
+__device__ __forceinline__ void run_chain(const Problem &p, const Layout &L, float *__restrict__ alpha_ws,
+                                          float *__restrict__ beta_ws, double *__restrict__ logp_ws,
+                                          float *__restrict__ loss, Lds<KIND, NL, VPL, NH> &lds, int NB1, int NB2, void *stamp_ws) {
+  using S_t = Side<KIND, NL, VPL, DIR, true>;
+  using LD = Lds<KIND, NL, VPL, NH>;
+  S_t S;
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x;
+  const int T = p.T, UP = L.UP;
+  S.lane = lane; S.UP = UP; S.blank = p.blank; S.SRS = L.SRS;
+  const int len = clampi(p.logit_length[b], 0, T);
+  S.len = len;
+  int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  const bool shape_ok = (ll <= p.U);
+  if (!shape_ok) ll = 0;
+  S.ll = ll;
+  S.own_rows = (DIR == 0 ? alpha_ws : beta_ws) + (long)b * (T + 1) * L.SRS;
+  S.oth_rows = (DIR == 0 ? beta_ws : alpha_ws) + (long)b * (T + 1) * L.SRS;
+  S.off = 0.0;
+  {
+    const int32_t *lab = p.labels + (long)b * p.label_stride;
+    auto tok = [&](int i) -> int { return (i >= 0 && i < ll) ? ((i < p.label_stride) ? lab[i] : p.blank) : -1 - (i < 0); };
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      int i = lane * NL + j;
+      int tk = tok(i);
+      S.norep[j] = (i == 0) || tk != tok(i - 1);
+      S.norep_next[j] = tok(i + 1) != tk;
+      S.c[j] = NEG;
+      S.o[j] = NEG;
+    }
+  }
+  const int tm = len / 2;
+  STAMP(Stamps st; st.begin());
+  if constexpr (DIR == 0) {
+    S.cx = 0.f;
+  } else {
+    S.cx = (ll == UP) ? 0.f : NEG;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      int i = lane * NL + j;
+      if (i == ll) S.c[j] = 0.f;
+      if (KIND == 0 && i == ll - 1) S.o[j] = 0.f;
+    }
+  }
+  S.spill(DIR == 0 ? 0 : len, 0.f, 0.f);
+  float *dump = lds.dump[DIR];
+
+  auto read_E = [&](const float *row, Emis<NL> &e) {
+    const float *q = row + lane * NL;
+    if constexpr (NL == 1) {
+      e.y[0] = q[0];
+    } else if constexpr (NL == 2) {
+      float2 v = *reinterpret_cast<const float2 *>(q);
+      e.y[0] = v.x; e.y[1] = v.y;
+    } else {
+#pragma unroll
+      for (int g = 0; g < NL / 4; ++g) {
+        float4 v = *reinterpret_cast<const float4 *>(q + 4 * g);
+        e.y[4 * g] = v.x; e.y[4 * g + 1] = v.y; e.y[4 * g + 2] = v.z; e.y[4 * g + 3] = v.w;
+      }
+    }
+    float4 tl = *reinterpret_cast<const float4 *>(row + LD::UP);  // same address in every lane: LDS broadcast
+    e.bl = tl.x; e.mx = tl.y; e.l2s = tl.z;
+  };
+  auto write_S = [&](float *row, const float (&s1)[NL], const float (&s2)[NL], float s0) {
+    float *q = row + 2 * lane * NL;
+    if constexpr (NL == 1) {
+      *reinterpret_cast<float2 *>(q) = make_float2(s1[0], s2[0]);
+    } else {
+#pragma unroll
+      for (int g = 0; g < NL / 2; ++g)
+        *reinterpret_cast<float4 *>(q + 4 * g) = make_float4(s1[2 * g], s2[2 * g], s1[2 * g + 1], s2[2 * g + 1]);
+    }
+    float *tq = (lane == 0) ? row + 2 * LD::UP : dump + lane;  // branch-free single-lane write
+    *tq = s0;
+  };
+
+  // ================= phase 1 =================
+  {
+    const int n1 = (DIR == 0) ? tm : len - tm;
+    const int t0 = (DIR == 0) ? 0 : len - 1;
+    const int myb = (n1 + BLK - 1) / BLK;
+    for (int it = 0; it <= NB1; ++it) {
+      const int blk = it - 1;
+      if (blk >= 0 && blk < myb) {
+        const float(*E)[LD::ES] = lds.E[DIR][blk & 1];
+        const int k0 = blk * BLK;
+        const int nv = (n1 - k0 < BLK) ? n1 - k0 : BLK;
+        if (nv == BLK) {
+#pragma unroll
+          for (int d = 0; d < BLK; ++d) {
+            Emis<NL> e;
+            read_E(E[d], e);
+            S.step(e);
+            if (d == BLK - 1) S.renorm();
+            const int t = DIR == 0 ? t0 + k0 + d : t0 - k0 - d;
+            S.spill(DIR == 0 ? t + 1 : t, 0.f, 0.f);
+          }
+        } else {
+          for (int d = 0; d < nv; ++d) {
+            Emis<NL> e;
+            read_E(E[d], e);
+            S.step(e);
+            const int t = DIR == 0 ? t0 + k0 + d : t0 - k0 - d;
+            S.spill(DIR == 0 ? t + 1 : t, 0.f, 0.f);
+          }
+        }
+      }
+      STAMP(st.mid());
+      block_barrier();
+      STAMP(st.end());
+    }
+  }
+
+  STAMP(st.phase1_done());
+  // ================= meeting point =================
+  __syncthreads();  // full drain: spilled rows of both chains are in L2 before anybody reads them
+  double dlogp;
+  {
+    SRow<KIND, NL> r;
+    load_srow<KIND, NL>(r, S.oth_rows + (long)tm * L.SRS, lane, UP);
+    dlogp = S.meet(r);
+    if (!shape_ok) dlogp = -INFINITY;
+  }
+  if (DIR == 0 && lane == 0) {
+    logp_ws[b] = dlogp;
+    loss[b] = (dlogp == -INFINITY) ? INFINITY : (float)(-dlogp * LN2_D);
+    lds.feasible = (dlogp != -INFINITY);
+  }
+  __syncthreads();
+  if (dlogp == -INFINITY) dlogp = 0.0;  // infeasible: keep the barrier schedule; the helpers write zeros instead
+
+  // ================= phase 2 =================
+  // No global memory traffic at all on the chain here: the other side's lattice rows were staged in LDS by the helpers
+  // (R rows), the posterior exponents go back into the same LDS rows (S rows, in place).
+  {
+    const int n2 = (DIR == 0) ? len - tm : tm;
+    const int myb = (n2 + BLK - 1) / BLK;
+    auto read_R = [&](const float *row, SRow<KIND, NL> &r) {
+      if constexpr (KIND == 0) {
+        const float *q = row + 2 * lane * NL;
+        if constexpr (NL == 1) {
+          float2 v = *reinterpret_cast<const float2 *>(q);
+          r.a[0] = v.x; r.b[0] = v.y;
+        } else {
+#pragma unroll
+          for (int g = 0; g < NL / 2; ++g) {
+            float4 v = *reinterpret_cast<const float4 *>(q + 4 * g);
+            r.a[2 * g] = v.x; r.b[2 * g] = v.y; r.a[2 * g + 1] = v.z; r.b[2 * g + 1] = v.w;
+          }
+        }
+        r.tail = *reinterpret_cast<const float4 *>(row + 2 * LD::UP);
+      } else {
+        const float *q = row + lane * NL;
+        if constexpr (NL == 1) {
+          r.a[0] = q[0];
+        } else if constexpr (NL == 2) {
+          float2 v = *reinterpret_cast<const float2 *>(q);
+          r.a[0] = v.x; r.a[1] = v.y;
+        } else {
+#pragma unroll
+          for (int g = 0; g < NL / 4; ++g) {
+            float4 v = *reinterpret_cast<const float4 *>(q + 4 * g);
+            r.a[4 * g] = v.x; r.a[4 * g + 1] = v.y; r.a[4 * g + 2] = v.z; r.a[4 * g + 3] = v.w;
+          }
+        }
+        r.tail = *reinterpret_cast<const float4 *>(row + LD::UP);
+      }
+    };
+    for (int it = 0; it <= NB2 + 1; ++it) {
+      const int blk = it - 1;
+      if (blk >= 0 && blk < myb) {
+        const float(*E)[LD::ES] = lds.E[DIR][blk & 1];
+        float(*RR)[LD::RS] = lds.R[DIR][blk % 3];
+        const int k0 = blk * BLK;
+        const int nv = (n2 - k0 < BLK) ? n2 - k0 : BLK;
+        if (nv == BLK) {
+#pragma unroll
+          for (int d = 0; d < BLK; ++d) {
+            Emis<NL> e;
+            read_E(E[d], e);
+            SRow<KIND, NL> r;
+            read_R(RR[d], r);
+            float s1[NL], s2[NL], s0;
+            S.post_step(e, r, dlogp, s1, s2, s0);
+            write_S(RR[d], s1, s2, s0);
+            if (d == BLK - 1) S.renorm();
+          }
+        } else {
+          for (int d = 0; d < nv; ++d) {
+            Emis<NL> e;
+            read_E(E[d], e);
+            SRow<KIND, NL> r;
+            read_R(RR[d], r);
+            float s1[NL], s2[NL], s0;
+            S.post_step(e, r, dlogp, s1, s2, s0);
+            write_S(RR[d], s1, s2, s0);
+          }
+        }
+      }
+      STAMP(st.mid());
+      block_barrier();
+      STAMP(st.end());
+    }
+  }
+  STAMP(st.dump(reinterpret_cast<unsigned long long *>(stamp_ws) + ((long)b * (2 + 2 * NH) + DIR) * 4, lane));
+}
+
+// ------------------------------------------------------------------------------------------------
+// helper wavefront h of NH per side: frames d = h, h + NH, ... of every block (FPH = BLK / NH frames per block)
+// ------------------------------------------------------------------------------------------------
+template <int KIND, int NL, int VPL, int NH, int DIR>
+__device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, const float *__restrict__ alpha_ws,
+                                           const float *__restrict__ beta_ws, float2 *__restrict__ stats_ws,
+                                           const float *__restrict__ d_loss, float *__restrict__ grad,
+                                           Lds<KIND, NL, VPL, NH> &lds, int NB1, int NB2, int h, void *stamp_ws) {
+  constexpr int V = 256 * VPL;
+  constexpr int FPH = BLK / NH;
+  using S_t = Side<KIND, NL, VPL, DIR, true>;
+  using LD = Lds<KIND, NL, VPL, NH>;
+  S_t S;
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x;
+  const int T = p.T;
+  S.lane = lane; S.UP = L.UP; S.blank = p.blank;
+  const int len = clampi(p.logit_length[b], 0, T);
+  int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  if (ll > p.U) ll = 0;
+  S.ll = ll;
+  S.xbase = p.logits + (long)b * T * V;
+  S.gbase = grad + (long)b * T * V;
+  S.xs = lds.xcopy[DIR * NH + h];  // single gather copy per helper (parity argument of gather/emit is always 0 here)
+  S.bins = lds.bins[DIR * NH + h];
+  S.dl = d_loss ? d_loss[b] : 1.0f;
+  {
+    const int32_t *lab = p.labels + (long)b * p.label_stride;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      int i = lane * NL + j;
+      int tk = (i < ll) ? ((i < p.label_stride) ? lab[i] : p.blank) : -1;
+      S.tokoff[j] = 4 * ((tk >= 0 && tk < V && tk != p.blank) ? tk : V);
+    }
+#pragma unroll
+    for (int q = 0; q < VPL; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) S.mb[4 * q + e] = (256 * q + lane * 4 + e == p.blank) ? 1.f : 0.f;
+  }
+  if (lane == 0) S.xs[V] = -6.0e29f;
+  float2 *stats = stats_ws + (long)b * T;
+  float *dump = lds.dump[2 + DIR * NH + h];
+  const int tm = len / 2;
+  STAMP(Stamps st; st.begin());
+
+  auto write_E = [&](float *row, const Emis<NL> &e) {
+    float *q = row + lane * NL;
+    if constexpr (NL == 1) {
+      q[0] = e.y[0];
+    } else if constexpr (NL == 2) {
+      *reinterpret_cast<float2 *>(q) = make_float2(e.y[0], e.y[1]);
+    } else {
+#pragma unroll
+      for (int g = 0; g < NL / 4; ++g)
+        *reinterpret_cast<float4 *>(q + 4 * g) = make_float4(e.y[4 * g], e.y[4 * g + 1], e.y[4 * g + 2], e.y[4 * g + 3]);
+    }
+    float *tq = (lane == 0) ? row + LD::UP : dump + (lane & 15) * 4;  // lanes >= 16 overlap in the sink: harmless
+    *reinterpret_cast<float4 *>(tq) = make_float4(e.bl, e.mx, e.l2s, 0.f);
+  };
+
+  // ================= phase 1: E stage with statistics (recorded for the other side's pass over the same frames) =========
+  {
+    const int n1 = (DIR == 0) ? tm : len - tm;
+    const int t0 = (DIR == 0) ? 0 : len - 1;
+    const int myb = (n1 + BLK - 1) / BLK;
+    auto fr = [&](int k) -> int {
+      int kk = k < n1 ? k : n1 - 1;
+      kk = kk < 0 ? 0 : kk;
+      int t = DIR == 0 ? t0 + kk : t0 - kk;
+      return t < 0 ? 0 : t;
+    };
+    float4 xb[FPH][VPL];  // this helper's rows of the next block to process
+    if (n1 > 0) static_for<0, FPH>([&](auto Q) { S.load_x(xb[decltype(Q)::value], fr(h + NH * decltype(Q)::value)); });
+    for (int it = 0; it <= NB1; ++it) {
+      const int blk = it;
+      if (blk < myb) {
+        float(*E)[LD::ES] = lds.E[DIR][blk & 1];
+        const int k0 = blk * BLK;
+        const int nv = (n1 - k0 < BLK) ? n1 - k0 : BLK;
+        float smx = 0.f, sl2 = 0.f;  // lane d keeps the statistics of frame d of the block
+        if (nv == BLK) {
+          static_for<0, FPH>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            const int d = h + NH * q;
+            Emis<NL> e;
+            S.emit(xb[q], 0, e);
+            write_E(E[d], e);
+            smx = (lane == d) ? e.mx : smx;
+            sl2 = (lane == d) ? e.l2s : sl2;
+          });
+          static_for<0, FPH>([&](auto Q) { S.load_x(xb[decltype(Q)::value], fr(k0 + BLK + h + NH * decltype(Q)::value)); });
+        } else {
+          for (int d = h; d < nv; d += NH) {
+            float4 xr[VPL];
+            S.load_x(xr, fr(k0 + d));
+            Emis<NL> e;
+            S.emit(xr, 0, e);
+            write_E(E[d], e);
+            smx = (lane == d) ? e.mx : smx;
+            sl2 = (lane == d) ? e.l2s : sl2;
+          }
+        }
+        if (lane < nv && (lane % NH) == h) stats[fr(k0 + lane)] = make_float2(smx, sl2);
+      }
+      STAMP(st.mid());
+      block_barrier();
+      STAMP(st.end());
+    }
+  }
+
+  STAMP(st.phase1_done());
+  // ================= meeting point =================
+  __syncthreads();
+  __syncthreads();
+  const bool feasible = lds.feasible != 0;
+
+  // ================= phase 2: E stage (statistics from the record) + G stage two blocks behind =================
+  {
+    const int n2 = (DIR == 0) ? len - tm : tm;
+    const int t0 = (DIR == 0) ? tm : tm - 1;
+    const int myb = (n2 + BLK - 1) / BLK;
+    auto fr = [&](int k) -> int {
+      int kk = k < n2 ? k : n2 - 1;
+      kk = kk < 0 ? 0 : kk;
+      int t = DIR == 0 ? t0 + kk : t0 - kk;
+      return t < 0 ? 0 : t;
+    };
+    if (h == 0) {
+      if (!feasible) {  // zero gradient for the whole sample (base_loss.py:283-288); barrier schedule unchanged
+        if constexpr (DIR == 0) S.zero_rows(tm, T); else S.zero_rows(0, tm);
+      } else if (DIR == 0) {
+        S.zero_rows(len, T);  // padded frames (base_loss.py:291-296)
+      }
+    }
+    // the other side's lattice rows, staged into LDS one block ahead of the chain (HBM -> registers -> LDS)
+    const float *oth = (DIR == 0 ? beta_ws : alpha_ws) + (long)b * (T + 1) * L.SRS;
+    auto orow = [&](int t) -> const float * {
+      const int idx = (DIR == 0) ? t + 1 : (KIND == 0 ? t + 1 : t);
+      return oth + (long)idx * L.SRS;
+    };
+    constexpr int MAINF = (KIND == 0 ? 2 : 1) * NL;  // floats of the row body per lane
+    struct RReg { float m[MAINF]; float4 tl; };
+    auto load_r = [&](RReg &r, int t) __attribute__((always_inline)) {
+      const float *row = orow(t);
+      const float *q = row + lane * MAINF;
+      if constexpr (MAINF == 1) r.m[0] = q[0];
+      else if constexpr (MAINF == 2) { float2 v = *reinterpret_cast<const float2 *>(q); r.m[0] = v.x; r.m[1] = v.y; }
+      else {
+#pragma unroll
+        for (int g = 0; g < MAINF / 4; ++g) {
+          float4 v = *reinterpret_cast<const float4 *>(q + 4 * g);
+          r.m[4 * g] = v.x; r.m[4 * g + 1] = v.y; r.m[4 * g + 2] = v.z; r.m[4 * g + 3] = v.w;
+        }
+      }
+      r.tl = *reinterpret_cast<const float4 *>(row + MAINF * 64 + 4 * (lane & 1));  // lanes 0/1 carry the two tail halves
+    };
+    auto stage_r = [&](float *lrow, const RReg &r) __attribute__((always_inline)) {
+      float *q = lrow + lane * MAINF;
+      if constexpr (MAINF == 1) q[0] = r.m[0];
+      else if constexpr (MAINF == 2) *reinterpret_cast<float2 *>(q) = make_float2(r.m[0], r.m[1]);
+      else {
+#pragma unroll
+        for (int g = 0; g < MAINF / 4; ++g)
+          *reinterpret_cast<float4 *>(q + 4 * g) = make_float4(r.m[4 * g], r.m[4 * g + 1], r.m[4 * g + 2], r.m[4 * g + 3]);
+      }
+      float *tq = (lane < 2) ? lrow + MAINF * 64 + 4 * lane : dump + (lane & 15) * 4;
+      *reinterpret_cast<float4 *>(tq) = make_float4(r.tl.x, r.tl.y, r.tl.z, r.tl.w);  // element-wise: keeps rr[] in registers
+    };
+    float4 xb[FPH][VPL];
+    float4 xg1[FPH][VPL], xg2[FPH][VPL];  // the logits rows of the two previous blocks: the G stage needs them again
+    static_for<0, FPH>([&](auto Q) {
+#pragma unroll
+      for (int c = 0; c < VPL; ++c) { xg1[decltype(Q)::value][c] = make_float4(0.f, 0.f, 0.f, 0.f); xg2[decltype(Q)::value][c] = xg1[decltype(Q)::value][c]; }
+    });
+    RReg rr[FPH];
+    float2 st_cur = make_float2(0.f, 0.f), st_next = make_float2(0.f, 0.f);
+    if (n2 > 0) {
+      static_for<0, FPH>([&](auto Q) {
+        S.load_x(xb[decltype(Q)::value], fr(h + NH * decltype(Q)::value));
+        load_r(rr[decltype(Q)::value], fr(h + NH * decltype(Q)::value));
+      });
+      st_cur = stats[fr(lane)];
+    }
+    for (int it = 0; it <= NB2 + 1; ++it) {
+      // ---- G stage loads first (block it-2): rows come from L2, their latency hides behind the E stage ----
+      const int gblk = it - 2;
+      const bool do_g = feasible && gblk >= 0 && gblk < myb;
+      float2 gst = make_float2(0.f, 0.f);
+      if (do_g) gst = stats[fr(gblk * BLK + lane)];
+      // ---- E stage (block it) ----
+      const int blk = it;
+      float4 xe[FPH][VPL];  // rows of block `it` (full blocks only; partial blocks reload in the G stage)
+      static_for<0, FPH>([&](auto Q) {
+#pragma unroll
+        for (int c = 0; c < VPL; ++c) xe[decltype(Q)::value][c] = xg1[decltype(Q)::value][c];
+      });
+      if (blk < myb) {
+        float(*E)[LD::ES] = lds.E[DIR][blk & 1];
+        float(*RR)[LD::RS] = lds.R[DIR][blk % 3];
+        const int k0 = blk * BLK;
+        const int nv = (n2 - k0 < BLK) ? n2 - k0 : BLK;
+        st_next = stats[fr(k0 + BLK + lane)];
+        if (nv == BLK) {
+          static_for<0, FPH>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            const int d = h + NH * q;
+            Emis<NL> e;
+            S.gather(xb[q], 0, readlane_f(st_cur.x, d), readlane_f(st_cur.y, d), e);
+            write_E(E[d], e);
+            stage_r(RR[d], rr[q]);
+#pragma unroll
+            for (int c = 0; c < VPL; ++c) xe[q][c] = xb[q][c];
+          });
+          static_for<0, FPH>([&](auto Q) {
+            S.load_x(xb[decltype(Q)::value], fr(k0 + BLK + h + NH * decltype(Q)::value));
+            load_r(rr[decltype(Q)::value], fr(k0 + BLK + h + NH * decltype(Q)::value));
+          });
+        } else {
+          for (int d = h; d < nv; d += NH) {
+            float4 xr[VPL];
+            RReg r1;
+            S.load_x(xr, fr(k0 + d));
+            load_r(r1, fr(k0 + d));
+            float2 sd = stats[fr(k0 + d)];
+            Emis<NL> e;
+            S.gather(xr, 0, sd.x, sd.y, e);
+            write_E(E[d], e);
+            stage_r(RR[d], r1);
+          }
+        }
+        st_cur = st_next;
+      }
+      // ---- G stage (block it-2): posterior scatter + gradient rows ----
+      if (do_g) {
+        const float(*SR)[LD::RS] = lds.R[DIR][gblk % 3];
+        const int k0 = gblk * BLK;
+        const int nv = (n2 - k0 < BLK) ? n2 - k0 : BLK;
+        auto g_frame = [&](int d, const float4(&xr)[VPL], float mx, float l2s) __attribute__((always_inline)) {
+          const float *row = SR[d];
+          float s1[NL], s2[NL];
+          const float *q = row + 2 * lane * NL;
+          if constexpr (NL == 1) {
+            float2 v = *reinterpret_cast<const float2 *>(q);
+            s1[0] = v.x; s2[0] = v.y;
+          } else {
+#pragma unroll
+            for (int g = 0; g < NL / 2; ++g) {
+              float4 v = *reinterpret_cast<const float4 *>(q + 4 * g);
+              s1[2 * g] = v.x; s2[2 * g] = v.y; s1[2 * g + 1] = v.z; s2[2 * g + 1] = v.w;
+            }
+          }
+          const float s0 = row[2 * LD::UP];
+          Emis<NL> e;
+          e.mx = mx; e.l2s = l2s;
+          S.grad_row(fr(k0 + d), s1, s2, s0, xr, e);
+        };
+        if (nv == BLK) {
+          static_for<0, FPH>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            const int d = h + NH * q;
+            g_frame(d, xg2[q], readlane_f(gst.x, d), readlane_f(gst.y, d));
+          });
+        } else {
+          for (int d = h; d < nv; d += NH) {
+            float4 xr[VPL];
+            S.load_x(xr, fr(k0 + d));
+            float2 sd = stats[fr(k0 + d)];
+            g_frame(d, xr, sd.x, sd.y);
+          }
+        }
+      }
+      static_for<0, FPH>([&](auto Q) {  // rotate: block it-1 -> it-2, block it -> it-1
+#pragma unroll
+        for (int c = 0; c < VPL; ++c) { xg2[decltype(Q)::value][c] = xg1[decltype(Q)::value][c]; xg1[decltype(Q)::value][c] = xe[decltype(Q)::value][c]; }
+      });
+      STAMP(st.mid());
+      block_barrier();
+      STAMP(st.end());
+    }
+  }
+  STAMP(st.dump(reinterpret_cast<unsigned long long *>(stamp_ws) + ((long)b * (2 + 2 * NH) + 2 + DIR * NH + h) * 4, lane));
+}
+
+// Wavefront roles: 0 = chain A, 1 = chain B, 2 .. 2+NH-1 = helpers of side A, then the helpers of side B.
+template <int KIND, int NL, int VPL, int NH>
+__global__ __launch_bounds__(64 * (2 + 2 * NH)) void fused4_kernel(Problem p, Layout L, float *__restrict__ alpha_ws,
+                                                                    float *__restrict__ beta_ws,
+                                                                    double *__restrict__ logp_ws,
+                                                                    float2 *__restrict__ stats_ws,
+                                                                    float *__restrict__ loss,
+                                                                    const float *__restrict__ d_loss,
+                                                                    float *__restrict__ grad, void *stamp_ws) {
+  __shared__ __attribute__((aligned(16))) Lds<KIND, NL, VPL, NH> lds;
+  const int w = threadIdx.x >> 6;
+  // every wavefront derives the same block counts: the barrier schedule is identical by construction
+  const int len = clampi(p.logit_length[blockIdx.x], 0, p.T);
+  const int tm = len / 2;
+  const int nA1 = tm, nB1 = len - tm;
+  const int bA1 = (nA1 + BLK - 1) / BLK, bB1 = (nB1 + BLK - 1) / BLK;
+  const int NB1 = bA1 > bB1 ? bA1 : bB1;
+  const int NB2 = NB1;  // phase 2 swaps the ranges: A takes len - tm frames, B takes tm
+  if (w == 0) {
+    __builtin_amdgcn_s_setprio(3);  // the sequential chains win issue arbitration against co-resident helpers
+    run_chain<KIND, NL, VPL, NH, 0>(p, L, alpha_ws, beta_ws, logp_ws, loss, lds, NB1, NB2, stamp_ws);
+  } else if (w == 1) {
+    __builtin_amdgcn_s_setprio(3);
+    run_chain<KIND, NL, VPL, NH, 1>(p, L, alpha_ws, beta_ws, logp_ws, loss, lds, NB1, NB2, stamp_ws);
+  } else if (w < 2 + NH) {
+    run_helper<KIND, NL, VPL, NH, 0>(p, L, alpha_ws, beta_ws, stats_ws, d_loss, grad, lds, NB1, NB2, w - 2, stamp_ws);
+  } else {
+    run_helper<KIND, NL, VPL, NH, 1>(p, L, alpha_ws, beta_ws, stats_ws, d_loss, grad, lds, NB1, NB2, w - 2 - NH, stamp_ws);
+  }
+}
+
+}  // namespace fused4
+
+template <int NL, int VPL>
+static void launch4_v(const Problem &p, const Layout &L, float *a, float *b, double *lp, float2 *stats, float *loss,
+                      const float *d_loss, float *grad, void *stamp, hipStream_t st) {
+  // helpers per side: 4 at V = 256 (ten wavefronts per utterance), 2 for wider vocabularies (LDS and register budget)
+  constexpr int NH = 4;
+  hipLaunchKernelGGL((fused4::fused4_kernel<CTC_FUSED_KIND, NL, VPL, NH>), dim3(p.B), dim3(64 * (2 + 2 * NH)), 0, st, p, L,
+                     a, b, lp, stats, loss, d_loss, grad, stamp);
+}
+
+template <int NL>
+static hipError_t launch4_nl(const Problem &p, const Layout &L, float *a, float *b, double *lp, float2 *stats,
+                             float *loss, const float *d_loss, float *grad, void *stamp, hipStream_t st) {
+  switch (p.V / 256) {
+    case 1: launch4_v<NL, 1>(p, L, a, b, lp, stats, loss, d_loss, grad, stamp, st); break;
+    default: return hipErrorInvalidValue;  // wider vocabularies: LDS budget -> ctc_fused.hip
+  }
+  return hipGetLastError();
+}
+
+#if CTC_FUSED_KIND == 0
+hipError_t run_fused4_classic
+#else
+hipError_t run_fused4_simplified
+#endif
+    (const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
+  float *alpha = reinterpret_cast<float *>(ws + L.off_alpha);
+  float *beta = reinterpret_cast<float *>(ws + L.off_beta);
+  double *logp = reinterpret_cast<double *>(ws + L.off_logp);
+  float2 *stats = reinterpret_cast<float2 *>(ws + L.off_emis);  // the emission region of the v1 pipeline is free here
+  void *stamp = ws + L.off_dummy;  // diagnostic builds (-DCTC_FUSED4_STAMPS) write per-wavefront cycle counts here
+  switch (L.NL) {
+    case 1: return launch4_nl<1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
+    case 2: return launch4_nl<2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace ctc

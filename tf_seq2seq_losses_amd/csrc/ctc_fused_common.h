@@ -1,0 +1,438 @@
+// Building blocks shared by the fused loss+gradient kernels (ctc_fused.hip: two self-contained wavefronts per
+// utterance; ctc_fused4.hip: chain + helper wavefronts).  See those files for the algorithms.
+#pragma once
+#include <type_traits>
+
+#include "ctc_common.h"
+
+namespace ctc {
+
+namespace fused {
+
+// Compile-time loop: f(std::integral_constant<int, I>) for I in [0, N).  Used instead of `#pragma unroll` where a
+// register-resident array is indexed by the loop variable: the index is a constant already in the front end, so the
+// array is scalarised even when the late loop unroller would run after SROA (otherwise it lands in scratch memory).
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+constexpr int PF = 16;   // logits rows of look-ahead (= unrolled block length = renormalisation period)
+constexpr int PFS = 8;   // spilled lattice rows of look-ahead in phase 2 (keeps the kernel inside 256 VGPRs)
+constexpr int NPACE = 48; // pacing stores after a ring prologue (see Side::pace)
+
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// ---- wave64 reductions with DPP (result broadcast through an SGPR) ----
+// Hand-written: hipcc lowers __builtin_amdgcn_update_dpp reductions to mov + mov_dpp + op per level (18 instructions
+// per reduction); here every level is ONE DPP-fused VALU op.  Lanes without a valid DPP source are disabled and keep
+// their value.  `s_nop 1` = the 2 wait states a DPP read of a VGPR written by the previous VALU op needs (hipcc pads
+// nothing inside asm).  After the row_shr scan lane 15 of each 16-lane row holds the row result; row_bcast:15 / :31
+// carry it into lane 63.
+#define CTC_WAVE_REDUCE_ASM(OP)                                                      \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"            \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"            \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"            \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"            \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"         \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"         \
+  "s_nop 0"
+
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  asm(CTC_WAVE_REDUCE_ASM("v_add_f32_dpp") : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  asm(CTC_WAVE_REDUCE_ASM("v_max_f32_dpp") : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// One spilled lattice row as the other side reads it: per lane NL slots of (first[, second]) plus the 16-byte tail.
+template <int KIND, int NL>
+struct SRow {
+  float a[NL];   // classic: closed part / simplified: the state
+  float b[NL];   // classic: open part (unused for simplified)
+  float4 tail;   // (state outside the slot range, -, off_hi, off_lo)
+  float2 stat;   // (row max, log2 sum exp) of the frame the reader processes with this row
+};
+
+template <int KIND, int NL>
+__device__ __forceinline__ void load_srow(SRow<KIND, NL> &r, const float *__restrict__ row, int lane, int UP) {
+  if constexpr (KIND == 0) {
+    const float *p = row + 2 * lane * NL;
+    if constexpr (NL == 1) {
+      float2 v = *reinterpret_cast<const float2 *>(p);
+      r.a[0] = v.x; r.b[0] = v.y;
+    } else {
+#pragma unroll
+      for (int q = 0; q < NL / 2; ++q) {
+        float4 v = *reinterpret_cast<const float4 *>(p + 4 * q);
+        r.a[2 * q] = v.x; r.b[2 * q] = v.y; r.a[2 * q + 1] = v.z; r.b[2 * q + 1] = v.w;
+      }
+    }
+    r.tail = *reinterpret_cast<const float4 *>(row + 2 * UP);
+    r.stat = *reinterpret_cast<const float2 *>(row + 2 * UP + 4);
+  } else {
+    const float *p = row + lane * NL;
+    if constexpr (NL == 1) {
+      r.a[0] = p[0];
+    } else if constexpr (NL == 2) {
+      float2 v = *reinterpret_cast<const float2 *>(p);
+      r.a[0] = v.x; r.a[1] = v.y;
+    } else {
+#pragma unroll
+      for (int q = 0; q < NL / 4; ++q) {
+        float4 v = *reinterpret_cast<const float4 *>(p + 4 * q);
+        r.a[4 * q] = v.x; r.a[4 * q + 1] = v.y; r.a[4 * q + 2] = v.z; r.a[4 * q + 3] = v.w;
+      }
+    }
+    r.tail = *reinterpret_cast<const float4 *>(row + UP);
+    r.stat = *reinterpret_cast<const float2 *>(row + UP + 4);
+  }
+}
+
+template <int KIND, int NL>
+__device__ __forceinline__ void store_srow(float *__restrict__ row, int lane, int UP, const float (&a)[NL],
+                                           const float (&b)[NL], float4 tail, float2 stat) {
+  if constexpr (KIND == 0) {
+    float *p = row + 2 * lane * NL;
+    if constexpr (NL == 1) {
+      *reinterpret_cast<float2 *>(p) = make_float2(a[0], b[0]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < NL / 2; ++q)
+        *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(a[2 * q], b[2 * q], a[2 * q + 1], b[2 * q + 1]);
+    }
+    // 32-byte wave-uniform tail in ONE store instruction: even lanes write the first half, odd lanes the second
+    const bool odd = lane & 1;
+    *reinterpret_cast<float4 *>(row + 2 * UP + (odd ? 4 : 0)) =
+        make_float4(odd ? stat.x : tail.x, odd ? stat.y : tail.y, odd ? 0.f : tail.z, odd ? 0.f : tail.w);
+  } else {
+    float *p = row + lane * NL;
+    if constexpr (NL == 1) {
+      p[0] = a[0];
+    } else if constexpr (NL == 2) {
+      *reinterpret_cast<float2 *>(p) = make_float2(a[0], a[1]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < NL / 4; ++q)
+        *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+    }
+    const bool odd = lane & 1;
+    *reinterpret_cast<float4 *>(row + UP + (odd ? 4 : 0)) =
+        make_float4(odd ? stat.x : tail.x, odd ? stat.y : tail.y, odd ? 0.f : tail.z, odd ? 0.f : tail.w);
+  }
+}
+
+// Per-frame emissions in base-2 logs.
+template <int NL>
+struct Emis {
+  float y[NL];
+  float bl, mx, l2s;
+};
+
+// The whole per-side program.  DIR 0 = side A (alpha, forward), DIR 1 = side B (beta, backward).
+// Slot i = lane*NL + j is label position i.  State convention (same as Scan in ctc_kernels.hip):
+//   classic    A: c[j] = closed(l=i+1), o[j] = open(l=i+1), cx = closed(l=0)
+//              B: c[j] = closed(l=i),   o[j] = open(l=i+1), cx = closed(l=UP)
+//   simplified A: c[j] = a(l=i+1), cx = a(l=0);   B: c[j] = b(l=i), cx = b(l=UP)
+// Rows are spilled in the layout the OTHER side's slots are aligned with:
+//   A -> rows[t] : slot i = (state_c(l=i) [, open(l=i+1)]), tail.x = state_c(l=UP)       (read by B)
+//   B -> rows[t] : slot i = (state_c(l=i+1) [, open(l=i+1)]), tail.x = state_c(l=0)      (read by A)
+template <int KIND, int NL, int VPL, int DIR, bool LOGITS>
+struct Side {
+  static constexpr int V = 256 * VPL;
+  // lattice state
+  float c[NL], o[NL], cx;
+  double off;
+  bool norep[NL], norep_next[NL];
+  int tokoff[NL];  // byte offset of label[i] inside the LDS copy of the logits row (pad slot for i >= label_length)
+  float mb[4 * VPL];  // 1.0 at this lane's element that is the blank column, else 0
+  // geometry
+  int lane, UP, len, ll, blank;
+  const float *xbase;   // logits of this utterance
+  float *gbase;         // gradient of this utterance
+  float *own_rows;      // spill rows this side writes
+  const float *oth_rows;  // spill rows the other side writes
+  int SRS;
+  float *sink;  // global: 1 KB per wavefront, target of the pacing stores of the ring prologues
+  float *xs;    // LDS: 2 x (V + 4) floats, gather copies of the logits row
+  float *bins;  // LDS: V floats, posterior per token
+  float dl;
+
+  __device__ __forceinline__ int frame(int t0, int k) const { return DIR == 0 ? t0 + k : t0 - k; }
+
+  // Pacing store.  hipcc derives the s_waitcnt vmcnt(N) of a software-pipelined loop from the LEAST number of memory
+  // operations it can prove to lie between a prefetch and its use, and that minimum comes from the ring prologue where
+  // the prefetches would be back to back.  Giving every prologue slot as many memory operations as a steady-state step
+  // has makes the derived N as large as in the steady state, so a wait never reaches stores/loads of the last few steps.
+  __device__ __forceinline__ void pace(int slot) const {
+    volatile float *q = sink + lane * 4;  // volatile: identical stores to one address must not be merged away
+    q[0] = (float)slot;
+  }
+
+  __device__ __forceinline__ void load_x(float4 (&xr)[VPL], int t) const {
+    const float *row = xbase + (long)t * V + lane * 4;
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) xr[q] = *reinterpret_cast<const float4 *>(row + 256 * q);
+  }
+
+  // log-softmax statistics (tools.py:27-40): row max and log2 sum exp by DPP reductions
+  __device__ __forceinline__ void stats(const float4 (&xr)[VPL], float &mx, float &l2s) const {
+    mx = 0.f; l2s = 0.f;
+    if constexpr (LOGITS) {
+      float m = fmaxf(fmaxf(xr[0].x, xr[0].y), fmaxf(xr[0].z, xr[0].w));
+#pragma unroll
+      for (int q = 1; q < VPL; ++q) m = fmaxf(m, fmaxf(fmaxf(xr[q].x, xr[q].y), fmaxf(xr[q].z, xr[q].w)));
+      mx = wave_max_dpp(m);
+      mx = (mx == -INFINITY) ? 0.f : mx;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < VPL; ++q)
+        s += fexp2((xr[q].x - mx) * LOG2E) + fexp2((xr[q].y - mx) * LOG2E) + fexp2((xr[q].z - mx) * LOG2E) +
+             fexp2((xr[q].w - mx) * LOG2E);
+      l2s = flog2(wave_sum_dpp(s));
+    }
+  }
+
+  // emission gather through an LDS copy of the row (base_loss.py:328-344, 365-371), split in two so that the LDS
+  // round trip of frame t+1 is in flight while frame t is processed: gather_issue early, gather_finish late.
+  struct Raw { float xg[NL]; float xb; };
+  __device__ __forceinline__ void gather_issue(const float4 (&xr)[VPL], int parity, Raw &w) const {
+    float *buf = xs + parity * (V + 4);
+#pragma unroll
+    for (int q = 0; q < VPL; ++q)  // element-wise rebuild: a whole-float4 copy out of the register ring keeps the ring in scratch
+      *reinterpret_cast<float4 *>(buf + 256 * q + lane * 4) = make_float4(xr[q].x, xr[q].y, xr[q].z, xr[q].w);
+    const char *bb = reinterpret_cast<const char *>(buf);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) w.xg[j] = *reinterpret_cast<const float *>(bb + tokoff[j]);
+    w.xb = buf[blank];
+  }
+  __device__ __forceinline__ void gather_finish(const Raw &w, float mx, float l2s, Emis<NL> &e) const {
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
+      e.y[j] = fmaxf((w.xg[j] - mx) * LOG2E - l2s, NEG);  // v_max returns the non-NaN operand: (-inf) - (-inf) -> sentinel
+    e.bl = fmaxf((w.xb - mx) * LOG2E - l2s, NEG);
+    e.mx = mx;
+    e.l2s = l2s;
+  }
+  __device__ __forceinline__ void gather(const float4 (&xr)[VPL], int parity, float mx, float l2s, Emis<NL> &e) const {
+    Raw w;
+    gather_issue(xr, parity, w);
+    gather_finish(w, mx, l2s, e);
+  }
+
+  __device__ __forceinline__ void emit(const float4 (&xr)[VPL], int parity, Emis<NL> &e) const {
+    float mx, l2s;
+    stats(xr, mx, l2s);
+    gather(xr, parity, mx, l2s, e);
+  }
+
+  // one lattice step (identical recursions to Scan::step in ctc_kernels.hip)
+  __device__ __forceinline__ void step(const Emis<NL> &e) {
+    const float bl = e.bl;
+    if constexpr (KIND == 0 && DIR == 0) {
+      float m[NL], x[NL];
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        m[j] = lse2(c[j], o[j]);
+        x[j] = norep_next[j] ? m[j] : c[j];
+      }
+      float xin0 = from_prev_lane(x[NL - 1], cx);
+#pragma unroll
+      for (int j = NL - 1; j >= 0; --j) {
+        float xin = (j == 0) ? xin0 : x[j - 1];
+        o[j] = e.y[j] + lse2(o[j], xin);
+        c[j] = bl + m[j];
+      }
+      cx += bl;
+    } else if constexpr (KIND == 0 && DIR == 1) {
+      float h[NL], ee[NL], pn[NL], x[NL];
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        h[j] = bl + c[j];
+        ee[j] = e.y[j] + o[j];
+        pn[j] = lse2(h[j], ee[j]);
+        x[j] = norep[j] ? pn[j] : h[j];
+      }
+      cx += bl;
+      float xinl = from_next_lane(x[0], cx);
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        float xin = (j == NL - 1) ? xinl : x[j + 1];
+        o[j] = lse2(xin, ee[j]);
+        c[j] = pn[j];
+      }
+    } else if constexpr (KIND == 1 && DIR == 0) {
+      float pin0 = from_prev_lane(c[NL - 1], cx);
+#pragma unroll
+      for (int j = NL - 1; j >= 0; --j) {
+        float pin = (j == 0) ? pin0 : c[j - 1];
+        c[j] = lse2(bl + c[j], e.y[j] + pin);
+      }
+      cx += bl;
+    } else {
+      float nin = from_next_lane(c[0], cx);
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        float nx = (j == NL - 1) ? nin : c[j + 1];
+        c[j] = lse2(bl + c[j], e.y[j] + nx);
+      }
+      cx += bl;
+    }
+  }
+
+  __device__ __forceinline__ void renorm() {
+    float mx = cx;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      mx = fmaxf(mx, c[j]);
+      if constexpr (KIND == 0) mx = fmaxf(mx, o[j]);
+    }
+    mx = wave_max_dpp(mx);
+    mx = (mx > NEG_THR) ? mx : 0.f;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      c[j] -= mx;
+      if constexpr (KIND == 0) o[j] -= mx;
+    }
+    cx -= mx;
+    off += (double)mx;
+  }
+
+  // spill the current state as lattice row `t` in the layout the other side is aligned with
+  __device__ __forceinline__ void spill(int t, float smx, float sl2s) const {
+    float cs[NL];
+    float tx;
+    if constexpr (DIR == 0) {  // slot i <- state_c(l=i): previous slot's c; tail <- state_c(l=UP): last slot's c
+#pragma unroll
+      for (int j = NL - 1; j > 0; --j) cs[j] = c[j - 1];
+      cs[0] = from_prev_lane(c[NL - 1], cx);
+      tx = readlane_f(c[NL - 1], 63);
+    } else {  // slot i <- state_c(l=i+1): next slot's c; tail <- state_c(l=0): first slot's c
+#pragma unroll
+      for (int j = 0; j < NL - 1; ++j) cs[j] = c[j + 1];
+      cs[NL - 1] = from_next_lane(c[0], cx);
+      tx = readlane_f(c[0], 0);
+    }
+    const float oh = (float)off;
+    store_srow<KIND, NL>(own_rows + (long)t * SRS, lane, UP, cs, o, make_float4(tx, 0.f, oh, (float)(off - (double)oh)),
+                         make_float2(smx, sl2s));
+  }
+
+  // log2 P at the meeting point from this side's state and the other side's row of the same time index
+  __device__ __forceinline__ double meet(const SRow<KIND, NL> &r) const {
+    float v[2 * NL + 1];
+    float m = cx + r.tail.x;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      v[2 * j] = c[j] + r.a[j];
+      v[2 * j + 1] = (KIND == 0) ? o[j] + r.b[j] : NEG;
+      m = fmaxf(m, fmaxf(v[2 * j], v[2 * j + 1]));
+    }
+    m = wave_max_dpp(m);
+    if (!(m > NEG_THR)) return -INFINITY;
+    float s = (lane == 0) ? fexp2(cx + r.tail.x - m) : 0.f;
+#pragma unroll
+    for (int j = 0; j < 2 * NL; ++j) s += fexp2(v[j] - m);
+    s = wave_sum_dpp(s);
+    return (double)m + (double)flog2(s) + off + (double)r.tail.z + (double)r.tail.w;
+  }
+
+  // posterior scatter + gradient row of frame t.  s1/s2/s0 are base-2 log posteriors of the blank parts, the token parts
+  // and the out-of-range blank part (see the table in the kernel body); xr is the logits row, e its statistics.
+  __device__ __forceinline__ void grad_row(int t, const float (&s1)[NL], const float (&s2)[NL], float s0,
+                                           const float4 (&xr)[VPL], const Emis<NL> &e) const {
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) *reinterpret_cast<float4 *>(bins + 256 * q + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    float qb = (lane == 0) ? fexp2(s0) : 0.f;
+    float qt[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      qb += fexp2(s1[j]);
+      qt[j] = fexp2(s2[j]);
+    }
+    // (no wave barrier needed: LDS ops of one wave execute in order and may-alias accesses keep program order)
+    char *bb = reinterpret_cast<char *>(bins);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) atomicAdd(reinterpret_cast<float *>(bb + tokoff[j]), qt[j]);  // pad slot absorbs i >= ll
+    qb = wave_sum_dpp(qb);
+    // (no wave barrier needed: LDS ops of one wave execute in order and may-alias accesses keep program order)
+    float *g = gbase + (long)t * V + lane * 4;
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) {
+      float4 pq = *reinterpret_cast<const float4 *>(bins + 256 * q + lane * 4);
+      pq.x += mb[4 * q] * qb; pq.y += mb[4 * q + 1] * qb; pq.z += mb[4 * q + 2] * qb; pq.w += mb[4 * q + 3] * qb;
+      float4 r;
+      if constexpr (LOGITS) {
+        r.x = dl * (fexp2((xr[q].x - e.mx) * LOG2E - e.l2s) - pq.x);
+        r.y = dl * (fexp2((xr[q].y - e.mx) * LOG2E - e.l2s) - pq.y);
+        r.z = dl * (fexp2((xr[q].z - e.mx) * LOG2E - e.l2s) - pq.z);
+        r.w = dl * (fexp2((xr[q].w - e.mx) * LOG2E - e.l2s) - pq.w);
+      } else {
+        r.x = -dl * pq.x; r.y = -dl * pq.y; r.z = -dl * pq.z; r.w = -dl * pq.w;
+      }
+      *reinterpret_cast<float4 *>(g + 256 * q) = r;
+    }
+    // (no wave barrier needed: LDS ops of one wave execute in order and may-alias accesses keep program order)
+  }
+
+  // phase-2 frame: posterior of frame t from this side's state and the other side's row, then the gradient row.
+  //   classic    A: after the step, state = alpha[t+1], r = beta[t+1]      B: before the step, state = beta[t+1], r = alpha[t+1]
+  //   simplified A: before the step, state = a[t], r = b[t+1]              B: before the step, state = b[t+1], r = a[t]
+  // (blank part, token part) per slot:  classic (c + r.a, o + r.b);  simplified A (c + bl + r.a, pin + y + r.a);
+  // simplified B (c + bl + r.a, r.a + y + next)   -- regroupings of classic_ctc_loss.py:565-669 / simplified_ctc_loss.py:456-534
+  // posterior exponents of one frame (+ the lattice step at the right place): fills s1 (blank parts), s2 (token parts), s0
+  __device__ __forceinline__ void post_step(const Emis<NL> &e, const SRow<KIND, NL> &r, double dlogp, float (&s1)[NL],
+                                            float (&s2)[NL], float &s0) {
+    if constexpr (KIND == 0 && DIR == 0) step(e);
+    const float sc = (float)((double)r.tail.z + (off - dlogp)) + r.tail.w;
+    if constexpr (KIND == 0) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) { s1[j] = c[j] + r.a[j] + sc; s2[j] = o[j] + r.b[j] + sc; }
+      s0 = cx + r.tail.x + sc;
+    } else if constexpr (DIR == 0) {
+      float pin0 = from_prev_lane(c[NL - 1], cx);
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        float pin = (j == 0) ? pin0 : c[j - 1];
+        s1[j] = c[j] + e.bl + r.a[j] + sc;
+        s2[j] = pin + e.y[j] + r.a[j] + sc;
+      }
+      s0 = cx + e.bl + r.tail.x + sc;
+    } else {
+      float nin = from_next_lane(c[0], cx);
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        float nx = (j == NL - 1) ? nin : c[j + 1];
+        s1[j] = c[j] + e.bl + r.a[j] + sc;
+        s2[j] = r.a[j] + e.y[j] + nx + sc;
+      }
+      s0 = cx + e.bl + r.tail.x + sc;
+    }
+    if constexpr (!(KIND == 0 && DIR == 0)) step(e);
+  }
+
+  __device__ __forceinline__ void frame2(int t, const float4 (&xr)[VPL], const Emis<NL> &e, const SRow<KIND, NL> &r, double dlogp) {
+    float s1[NL], s2[NL], s0;
+    post_step(e, r, dlogp, s1, s2, s0);
+    grad_row(t, s1, s2, s0, xr, e);
+  }
+
+  __device__ __forceinline__ void zero_rows(int t_from, int t_to) const {
+    for (int t = t_from; t < t_to; ++t) {
+      float *g = gbase + (long)t * V + lane * 4;
+#pragma unroll
+      for (int q = 0; q < VPL; ++q) *reinterpret_cast<float4 *>(g + 256 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+};
+
+}  // namespace fused
+}  // namespace ctc
