@@ -15,8 +15,8 @@ torch.cuda.synchronize()
 al=lambda x:(x+255)&~255
 NL=2; UP=128; ERS=UP+4; SRS=2*UP+8
 o=0; o=al(o+B*T*ERS*4); o=al(o+B*(T+1)*SRS*4); o=al(o+B*(T+1)*SRS*4); o=al(o+B*8); off_dummy=o
-NH=4; NW=2+2*NH
+NH=4; NW=4+2*NH
 st=ws[off_dummy:off_dummy+B*NW*32].view(torch.int64).cpu().numpy().reshape(B,NW,4)
-names=["chain A","chain B"]+[f"helper A{h}" for h in range(NH)]+[f"helper B{h}" for h in range(NH)]
+names=["main A","main B","recompute A","recompute B"]+[f"helper A{h}" for h in range(NH)]+[f"helper B{h}" for h in range(NH)]
 for i,nm in enumerate(names):
     print(f"{nm}: work {st[:,i,0].mean():.0f} (phase1 {st[:,i,2].mean():.0f}, phase2 {st[:,i,0].mean()-st[:,i,2].mean():.0f})  barrier-wait {st[:,i,1].mean():.0f} cycles")

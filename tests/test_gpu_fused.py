@@ -1,4 +1,4 @@
-"""The fused loss+gradient kernels (csrc/ctc_fused4.hip, csrc/ctc_fused.hip; V in {256, 512, 1024}, logits input) against the float64
+"""The fused loss+gradient kernels (csrc/ctc_fused5.hip, csrc/ctc_fused4.hip, csrc/ctc_fused.hip; V in {256, 512, 1024}, logits input) against the float64
 C oracle and against the three-kernel pipeline (CTC_AMD_PIPELINE=v1), including the edge cases the reference tests:
 ragged and zero lengths, infeasible samples, empty labels, repeated tokens, d_loss weighting."""
 import os
@@ -33,6 +33,7 @@ def _run(kind, logits, labels, ll, tl, pipeline, d_loss=None):
 
 
 def _check(kind, logits, labels, ll, tl, d_loss=None):
+    l5, g5 = _run(kind, logits, labels, ll, tl, "fused5", d_loss)
     lf, gf = _run(kind, logits, labels, ll, tl, "fused4", d_loss)
     l2, g2 = _run(kind, logits, labels, ll, tl, "fused2", d_loss)
     l1, g1 = _run(kind, logits, labels, ll, tl, "v1", d_loss)
@@ -40,7 +41,7 @@ def _check(kind, logits, labels, ll, tl, d_loss=None):
     if d_loss is not None:
         rg = rg * d_loss[:, None, None]
     fin = np.isfinite(rl)
-    for lo, gr, name in ((lf, gf, "fused4"), (l2, g2, "fused2"), (l1, g1, "v1")):
+    for lo, gr, name in ((l5, g5, "fused5"), (lf, gf, "fused4"), (l2, g2, "fused2"), (l1, g1, "v1")):
         assert np.array_equal(np.isfinite(lo), fin), name
         assert np.all(lo[~fin] == np.inf), name
         if fin.any():
@@ -78,7 +79,7 @@ def test_fused_edge_lengths(kind):
     rl, rg = C.loss_grad(kind, labels, logits, ll, tl_ref, 0)
     rg = rg * d_loss[:, None, None]
     fin = np.isfinite(rl)
-    for pipeline in ("fused4", "fused2"):
+    for pipeline in ("fused5", "fused4", "fused2"):
         lf, gf = _run(kind, logits, labels, ll, tl, pipeline, d_loss)
         assert np.array_equal(np.isfinite(lf), fin), pipeline
         assert (np.abs(lf[fin] - rl[fin]) / np.maximum(1, np.abs(rl[fin]))).max() < TOL, pipeline

@@ -12,6 +12,15 @@ hipError_t run_grad(const Problem &p, const Layout &L, char *ws, const float *d_
 hipError_t run_convert(const Problem &p, const Layout &L, char *ws, float *alpha_out, float *beta_out, hipStream_t st);
 hipError_t run_fused_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 hipError_t run_fused_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
+hipError_t run_fused5_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
+hipError_t run_fused5_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
+// shapes the checkpoint + recompute kernel (ctc_fused5.hip) is instantiated for: logits input, V = 256, U <= 128
+inline bool fused5_eligible(const Problem &p, const Layout &L) {
+  return p.wrt == 0 && p.V == 256 && L.NL <= 2 && p.B > 0 && p.T > 0;
+}
+inline hipError_t run_fused5(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
+  return p.kind == 0 ? run_fused5_classic(p, L, ws, loss, d_loss, grad, st) : run_fused5_simplified(p, L, ws, loss, d_loss, grad, st);
+}
 hipError_t run_fused4_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 hipError_t run_fused4_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 // shapes the chain + helper kernel (ctc_fused4.hip) is instantiated for: logits input, V = 256, U <= 128 (LDS budget)
@@ -103,12 +112,19 @@ int ctc_amd_loss_grad(int kind, int wrt, const float *logits, const int32_t *lab
   if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
   ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // pipeline selection: fused4 (ctc_fused4.hip: chain + helper wavefronts) > fused2 (ctc_fused.hip: two self-contained
-  // wavefronts) > v1 (emit -> scan -> grad), by shape eligibility.  CTC_AMD_PIPELINE=v1|fused2 forces a lower tier
-  // (the parity tests run all three).
+  // pipeline selection by shape eligibility: fused5 (ctc_fused5.hip: chains + recompute chains + helpers, no lattice
+  // spill) > fused4 (ctc_fused4.hip: chains + helpers, half of the lattice spilled) > fused2 (ctc_fused.hip: two
+  // self-contained wavefronts) > v1 (emit -> scan -> grad).  CTC_AMD_PIPELINE=v1|fused2|fused4 forces a lower tier
+  // (the parity tests run all of them).
   const char *pipe = getenv("CTC_AMD_PIPELINE");
   const bool force_v1 = pipe && pipe[0] == 'v' && pipe[1] == '1';
   const bool force_f2 = pipe && pipe[0] == 'f' && pipe[5] == '2';
+  const bool force_f4 = pipe && pipe[0] == 'f' && pipe[5] == '4';
+  if (grad && !force_v1 && !force_f2 && !force_f4 && ctc::fused5_eligible(p, L)) {
+    hipError_t ef = ctc::run_fused5(p, L, static_cast<char *>(workspace), loss, d_loss, grad, st);
+    if (ef != hipSuccess) return hip_fail(ef, "fused5 launch");
+    return CTC_AMD_OK;
+  }
   if (grad && !force_v1 && !force_f2 && ctc::fused4_eligible(p, L)) {
     hipError_t ef = ctc::run_fused4(p, L, static_cast<char *>(workspace), loss, d_loss, grad, st);
     if (ef != hipSuccess) return hip_fail(ef, "fused4 launch");

@@ -1,0 +1,715 @@
+// Fused loss + gradient kernel for gfx950, pipeline v4: NO lattice spill.  One workgroup of 4 + 2*NH wavefronts per
+// utterance (12 at NH = 4, three per SIMD of the CU that owns the utterance):
+//
+//   wave 0 / 1 : main chain A / B -- the lattice recursion only (alpha forward from frame 0, beta backward from frame
+//                len-1, meeting in the middle like ctc_fused.hip / ctc_fused4.hip).  Phase 1 leaves ONE checkpoint row per
+//                block in HBM (1/BLK of the rows ctc_fused4.hip spills).  Phase 2 reads everything from LDS.
+//   wave 2 / 3 : recompute chain for A / for B -- phase 2 only.  For the block its main chain will process next it restarts
+//                the OTHER side's recursion from that side's checkpoint and regenerates the BLK lattice rows into LDS
+//                (R rows): beta rows for A's blocks, alpha rows for B's.  It reuses the emissions the helpers already
+//                staged for that block (emissions do not depend on the direction).
+//   waves 4..  : NH helpers per side -- logits rows from HBM (prefetched a block ahead in registers), log-softmax
+//                statistics by DPP reductions, emission gather through an LDS copy of the row (E stage); posterior scatter
+//                with ds_add_f32 into an LDS token row and the softmax - posterior store (G stage).  The logits rows of a
+//                block stay in the helper's registers from its E stage to its G stage.
+//
+//   Pipeline per side, iteration `it`:  E(block it) -> recompute(block it-1) -> main(block it-2) -> G(block it-3);
+//   E and R/S rows are triple-buffered in LDS; all wavefronts meet at ONE raw s_barrier per iteration and derive the same
+//   iteration counts from logit_length, so barrier counts match by construction.
+//   Blocks live on an absolute grid of BLK frames; only the block that contains frame len-1 may be partial.
+//
+//   HBM traffic per utterance: logits read twice (once per phase), gradient written once, T/BLK checkpoint rows and
+//   8 bytes of softmax statistics per frame: ~1.55x the algorithmic 2*T*V*4 bytes (ctc_fused4.hip: 2.5x, v1: 4.4x).
+//
+// References: classic_ctc_loss.py:310-462,565-669, simplified_ctc_loss.py:291-438,456-534, base_loss.py:262-298,328-344,
+// 420-468, tools.py:27-40.  Eligibility: V = 256, U <= 128 (LDS budget); otherwise ctc_fused.hip / the v1 pipeline run.
+#include "ctc_fused_common.h"
+
+#ifndef CTC_FUSED_KIND
+#error "compile with -DCTC_FUSED_KIND=0 (classic) or 1 (simplified)"
+#endif
+
+namespace ctc {
+namespace fused5 {
+
+using namespace ctc::fused;
+
+__device__ __forceinline__ void block_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed; vmcnt untouched
+  __builtin_amdgcn_s_barrier();
+}
+
+#ifdef CTC_FUSED_STAMPS
+// Diagnostic build only: per-wavefront cycles spent working vs. waiting at the block barrier (written to the sink area).
+struct Stamps {
+  unsigned long long work = 0, wait = 0, t0 = 0, work1 = 0;
+  __device__ __forceinline__ void begin() { t0 = __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void mid() { unsigned long long t = __builtin_amdgcn_s_memtime(); work += t - t0; t0 = t; }
+  __device__ __forceinline__ void end() { unsigned long long t = __builtin_amdgcn_s_memtime(); wait += t - t0; t0 = t; }
+  __device__ __forceinline__ void phase1_done() { work1 = work; }
+  __device__ __forceinline__ void dump(unsigned long long *dst, int lane) {
+    if (lane == 0) { dst[0] = work; dst[1] = wait; dst[2] = work1; dst[3] = 0; }
+  }
+};
+#define STAMP(x) x
+#else
+#define STAMP(x)
+#endif
+
+template <int KIND, int NL, int NH, int BLK>
+struct Lds {
+  static constexpr int V = 256, UP = 64 * NL;
+  static constexpr int ES = UP + 4;      // E row: y[UP], bl, mx, l2s, -
+  static constexpr int RS = 2 * UP + 8;  // R row (recompute chain): the other side's lattice row in its HBM layout;
+                                         // S row (main chain, in place): (s1, s2) per slot, s0 at [2 UP]
+  static constexpr int NW = 4 + 2 * NH;
+  float E[2][3][BLK][ES];   // [side][block % 3]
+  float R[2][3][BLK][RS];   // [side][block % 3]
+  float xcopy[2 * NH][V + 4];
+  float bins[2 * NH][V + 4];
+  float dump[NW][64];
+  int feasible;
+};
+
+// Block geometry shared by every wavefront of the workgroup.
+template <int BLK>
+struct Geo {
+  int len, G, tmb, tm, NB;
+  __device__ __forceinline__ void init(int len_) {
+    len = len_;
+    G = (len + BLK - 1) / BLK;
+    tmb = G / 2;
+    tm = tmb * BLK;
+    NB = G - tmb;  // >= tmb: blocks per side and phase, as iteration bound
+  }
+  __device__ __forceinline__ int nvof(int g) const { int r = len - BLK * g; return r < BLK ? r : BLK; }
+  // side-local block j of (phase, side) -> absolute block; count of blocks
+  __device__ __forceinline__ int nblocks(int phase, int side) const { return (phase == 1) == (side == 0) ? tmb : G - tmb; }
+  __device__ __forceinline__ int absblock(int phase, int side, int j) const {
+    if (phase == 1) return side == 0 ? j : G - 1 - j;
+    return side == 0 ? tmb + j : tmb - 1 - j;
+  }
+  // frame processed at position d of block g by `side` (A ascending, B descending)
+  __device__ __forceinline__ int frame(int side, int g, int d) const { return side == 0 ? BLK * g + d : BLK * g + nvof(g) - 1 - d; }
+};
+
+template <int NL, class LDt>
+__device__ __forceinline__ void read_E(const float *row, int lane, Emis<NL> &e) {
+  const float *q = row + lane * NL;
+  if constexpr (NL == 1) {
+    e.y[0] = q[0];
+  } else {
+    float2 v = *reinterpret_cast<const float2 *>(q);
+    e.y[0] = v.x; e.y[1] = v.y;
+  }
+  float4 tl = *reinterpret_cast<const float4 *>(row + LDt::UP);  // same address in every lane: LDS broadcast
+  e.bl = tl.x; e.mx = tl.y; e.l2s = tl.z;
+}
+
+// lattice row (HBM layout of Layout::SRS floats) <-> LDS row
+template <int KIND, int NL, class LDt>
+__device__ __forceinline__ void read_R(const float *row, int lane, SRow<KIND, NL> &r) {
+  if constexpr (KIND == 0) {
+    const float *q = row + 2 * lane * NL;
+    if constexpr (NL == 1) {
+      float2 v = *reinterpret_cast<const float2 *>(q);
+      r.a[0] = v.x; r.b[0] = v.y;
+    } else {
+      float4 v = *reinterpret_cast<const float4 *>(q);
+      r.a[0] = v.x; r.b[0] = v.y; r.a[1] = v.z; r.b[1] = v.w;
+    }
+    r.tail = *reinterpret_cast<const float4 *>(row + 2 * LDt::UP);
+  } else {
+    const float *q = row + lane * NL;
+    if constexpr (NL == 1) {
+      r.a[0] = q[0];
+    } else {
+      float2 v = *reinterpret_cast<const float2 *>(q);
+      r.a[0] = v.x; r.a[1] = v.y;
+    }
+    r.tail = *reinterpret_cast<const float4 *>(row + LDt::UP);
+  }
+}
+template <int KIND, int NL, class LDt>
+__device__ __forceinline__ void write_R(float *row, float *dump, int lane, const float (&a)[NL], const float (&b)[NL], float4 tail) {
+  if constexpr (KIND == 0) {
+    float *q = row + 2 * lane * NL;
+    if constexpr (NL == 1) *reinterpret_cast<float2 *>(q) = make_float2(a[0], b[0]);
+    else *reinterpret_cast<float4 *>(q) = make_float4(a[0], b[0], a[1], b[1]);
+    float *tq = (lane == 0) ? row + 2 * LDt::UP : dump + (lane & 15) * 4;
+    *reinterpret_cast<float4 *>(tq) = tail;
+  } else {
+    float *q = row + lane * NL;
+    if constexpr (NL == 1) q[0] = a[0];
+    else *reinterpret_cast<float2 *>(q) = make_float2(a[0], a[1]);
+    float *tq = (lane == 0) ? row + LDt::UP : dump + (lane & 15) * 4;
+    *reinterpret_cast<float4 *>(tq) = tail;
+  }
+}
+
+// state of a chain in the row layout the other side is aligned with (see Side::spill)
+template <int KIND, int NL, int DIR, class S_t>
+__device__ __forceinline__ void state_row(const S_t &S, float (&cs)[NL], float4 &tail) {
+  float tx;
+  if constexpr (DIR == 0) {
+#pragma unroll
+    for (int j = NL - 1; j > 0; --j) cs[j] = S.c[j - 1];
+    cs[0] = from_prev_lane(S.c[NL - 1], S.cx);
+    tx = readlane_f(S.c[NL - 1], 63);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NL - 1; ++j) cs[j] = S.c[j + 1];
+    cs[NL - 1] = from_next_lane(S.c[0], S.cx);
+    tx = readlane_f(S.c[0], 0);
+  }
+  const float oh = (float)S.off;
+  tail = make_float4(tx, 0.f, oh, (float)(S.off - (double)oh));
+}
+// inverse: a chain's native state from one of its own checkpoint rows
+template <int KIND, int NL, int DIR, class S_t>
+__device__ __forceinline__ void restore_state(S_t &S, const SRow<KIND, NL> &r) {
+  if constexpr (DIR == 0) {  // row slot i = state_c(l=i), tail = state_c(l=UP); native slot i = state_c(l=i+1), cx = l=0
+#pragma unroll
+    for (int j = 0; j < NL - 1; ++j) S.c[j] = r.a[j + 1];
+    S.c[NL - 1] = from_next_lane(r.a[0], r.tail.x);
+    S.cx = readlane_f(r.a[0], 0);
+  } else {  // row slot i = state_c(l=i+1), tail = state_c(l=0); native slot i = state_c(l=i), cx = l=UP
+#pragma unroll
+    for (int j = NL - 1; j > 0; --j) S.c[j] = r.a[j - 1];
+    S.c[0] = from_prev_lane(r.a[NL - 1], r.tail.x);
+    S.cx = readlane_f(r.a[NL - 1], 63);
+  }
+#pragma unroll
+  for (int j = 0; j < NL; ++j) S.o[j] = (KIND == 0) ? r.b[j] : NEG;
+  S.off = (double)r.tail.z + (double)r.tail.w;
+}
+
+template <int KIND, int NL, int DIR>
+__device__ __forceinline__ void init_labels(Side<KIND, NL, 1, DIR, true> &S, const Problem &p, int b, int lane, int ll) {
+  const int32_t *lab = p.labels + (long)b * p.label_stride;
+  auto tok = [&](int i) -> int { return (i >= 0 && i < ll) ? ((i < p.label_stride) ? lab[i] : p.blank) : -1 - (i < 0); };
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    int i = lane * NL + j;
+    int tk = tok(i);
+    S.norep[j] = (i == 0) || tk != tok(i - 1);
+    S.norep_next[j] = tok(i + 1) != tk;
+    S.tokoff[j] = 4 * ((tk >= 0 && tk < 256 && tk != p.blank) ? tk : 256);
+    S.c[j] = NEG;
+    S.o[j] = NEG;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) S.mb[e] = (lane * 4 + e == p.blank) ? 1.f : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// main chain
+// ------------------------------------------------------------------------------------------------
+template <int KIND, int NL, int NH, int BLK, int DIR>
+__device__ __forceinline__ void run_main(const Problem &p, const Layout &L, float *__restrict__ alpha_ws,
+                                         float *__restrict__ beta_ws, double *__restrict__ logp_ws,
+                                         float *__restrict__ loss, Lds<KIND, NL, NH, BLK> &lds, const Geo<BLK> &geo,
+                                         void *stamp_ws) {
+  using S_t = Side<KIND, NL, 1, DIR, true>;
+  using LD = Lds<KIND, NL, NH, BLK>;
+  S_t S;
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x;
+  const int T = p.T, UP = L.UP;
+  S.lane = lane; S.UP = UP; S.blank = p.blank; S.SRS = L.SRS;
+  const int len = geo.len;
+  S.len = len;
+  int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  const bool shape_ok = (ll <= p.U);
+  if (!shape_ok) ll = 0;
+  S.ll = ll;
+  S.own_rows = (DIR == 0 ? alpha_ws : beta_ws) + (long)b * (T + 1) * L.SRS;
+  S.oth_rows = (DIR == 0 ? beta_ws : alpha_ws) + (long)b * (T + 1) * L.SRS;
+  S.off = 0.0;
+  init_labels<KIND, NL, DIR>(S, p, b, lane, ll);
+  if constexpr (DIR == 0) {
+    S.cx = 0.f;
+  } else {
+    S.cx = (ll == UP) ? 0.f : NEG;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      int i = lane * NL + j;
+      if (i == ll) S.c[j] = 0.f;
+      if (KIND == 0 && i == ll - 1) S.o[j] = 0.f;
+    }
+  }
+  float *dump = lds.dump[DIR];
+  STAMP(Stamps st; st.begin());
+
+  // ================= phase 1: lattice steps, one checkpoint row per block =================
+  {
+    const int nb = geo.nblocks(1, DIR);
+    for (int it = 0; it <= geo.NB; ++it) {
+      const int j = it - 1;
+      if (j >= 0 && j < nb) {
+        const int g = geo.absblock(1, DIR, j);
+        const int nv = geo.nvof(g);
+        const float(*E)[LD::ES] = lds.E[DIR][j % 3];
+        // checkpoint: the state at the boundary this block starts from (alpha[BLK g] / beta[BLK g + nv])
+        S.spill(DIR == 0 ? BLK * g : BLK * g + nv, 0.f, 0.f);
+        if (nv == BLK) {
+#pragma unroll
+          for (int d = 0; d < BLK; ++d) {
+            Emis<NL> e;
+            read_E<NL, LD>(E[d], lane, e);
+            S.step(e);
+          }
+        } else {
+          for (int d = 0; d < nv; ++d) {
+            Emis<NL> e;
+            read_E<NL, LD>(E[d], lane, e);
+            S.step(e);
+          }
+        }
+        S.renorm();
+      }
+      STAMP(st.mid());
+      block_barrier();
+      STAMP(st.end());
+    }
+  }
+  S.spill(geo.tm, 0.f, 0.f);  // alpha[tm] / beta[tm]: the meeting row
+
+  STAMP(st.phase1_done());
+  // ================= meeting point =================
+  __syncthreads();  // full drain: the checkpoint rows of both chains are in L2 before anybody reads them
+  double dlogp;
+  {
+    SRow<KIND, NL> r;
+    load_srow<KIND, NL>(r, S.oth_rows + (long)geo.tm * L.SRS, lane, UP);
+    dlogp = S.meet(r);
+    if (!shape_ok) dlogp = -INFINITY;
+  }
+  if (DIR == 0 && lane == 0) {
+    logp_ws[b] = dlogp;
+    loss[b] = (dlogp == -INFINITY) ? INFINITY : (float)(-dlogp * LN2_D);
+    lds.feasible = (dlogp != -INFINITY);
+  }
+  __syncthreads();
+  if (dlogp == -INFINITY) dlogp = 0.0;  // infeasible: keep the barrier schedule; the helpers write zeros instead
+
+  // ================= phase 2: everything from LDS =================
+  {
+    const int nb = geo.nblocks(2, DIR);
+    for (int it = 0; it <= geo.NB + 2; ++it) {
+      const int j = it - 2;
+      if (j >= 0 && j < nb) {
+        const int g = geo.absblock(2, DIR, j);
+        const int nv = geo.nvof(g);
+        const float(*E)[LD::ES] = lds.E[DIR][j % 3];
+        float(*RR)[LD::RS] = lds.R[DIR][j % 3];
+        auto one = [&](int d) __attribute__((always_inline)) {
+          Emis<NL> e;
+          read_E<NL, LD>(E[d], lane, e);
+          SRow<KIND, NL> r;
+          read_R<KIND, NL, LD>(RR[d], lane, r);
+          float s1[NL], s2[NL], s0;
+          S.post_step(e, r, dlogp, s1, s2, s0);
+          float *row = RR[d];  // S row in place
+          float *q = row + 2 * lane * NL;
+          if constexpr (NL == 1) *reinterpret_cast<float2 *>(q) = make_float2(s1[0], s2[0]);
+          else *reinterpret_cast<float4 *>(q) = make_float4(s1[0], s2[0], s1[1], s2[1]);
+          float *tq = (lane == 0) ? row + 2 * LD::UP : dump + lane;
+          *tq = s0;
+        };
+        if (nv == BLK) {
+#pragma unroll
+          for (int d = 0; d < BLK; ++d) one(d);
+        } else {
+          for (int d = 0; d < nv; ++d) one(d);
+        }
+        S.renorm();
+      }
+      STAMP(st.mid());
+      block_barrier();
+      STAMP(st.end());
+    }
+  }
+  STAMP(st.dump(reinterpret_cast<unsigned long long *>(stamp_ws) + ((long)b * LD::NW + DIR) * 4, lane));
+}
+
+// ------------------------------------------------------------------------------------------------
+// recompute chain of side SIDE (phase 2): runs the OTHER direction's recursion inside one block, from that direction's
+// checkpoint, and leaves the rows its main chain needs in LDS.  R[d] = the row main needs at position d of the block:
+//   SIDE A (needs beta[t+1] at frame t = BLK g + d)      : R[nv-1] = checkpoint beta[BLK g + nv]; step frames downward
+//   SIDE B classic (needs alpha[t+1] at t = BLK g + nv-1-d): step frames upward from alpha[BLK g], row after each step
+//   SIDE B simplified (needs a[t])                        : row before each step
+// ------------------------------------------------------------------------------------------------
+template <int KIND, int NL, int NH, int BLK, int SIDE>
+__device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L, const float *__restrict__ alpha_ws,
+                                              const float *__restrict__ beta_ws, Lds<KIND, NL, NH, BLK> &lds,
+                                              const Geo<BLK> &geo, void *stamp_ws) {
+  constexpr int RDIR = 1 - SIDE;  // direction of the recursion this wave runs
+  using S_t = Side<KIND, NL, 1, RDIR, true>;
+  using LD = Lds<KIND, NL, NH, BLK>;
+  S_t S;
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x;
+  const int T = p.T, UP = L.UP;
+  S.lane = lane; S.UP = UP; S.blank = p.blank; S.SRS = L.SRS;
+  int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  if (ll > p.U) ll = 0;
+  S.ll = ll;
+  S.off = 0.0;
+  S.cx = NEG;
+  init_labels<KIND, NL, RDIR>(S, p, b, lane, ll);
+  // checkpoints of the direction this wave runs: written by the OTHER side's main chain in phase 1
+  const float *ck_rows = (RDIR == 0 ? alpha_ws : beta_ws) + (long)b * (T + 1) * L.SRS;
+  float *dump = lds.dump[2 + SIDE];
+  STAMP(Stamps st; st.begin());
+
+  for (int it = 0; it <= geo.NB; ++it) {  // phase 1: nothing to recompute
+    STAMP(st.mid());
+    block_barrier();
+    STAMP(st.end());
+  }
+  STAMP(st.phase1_done());
+  __syncthreads();
+  __syncthreads();
+
+  const int nb = geo.nblocks(2, SIDE);
+  auto ck_index = [&](int j) -> int {
+    int jj = j < nb ? j : nb - 1;
+    jj = jj < 0 ? 0 : jj;
+    const int g = geo.absblock(2, SIDE, jj);
+    int idx = (SIDE == 0) ? BLK * g + geo.nvof(g) : BLK * g;  // beta at the upper boundary / alpha at the lower one
+    return idx < 0 ? 0 : idx;
+  };
+  SRow<KIND, NL> ck_next;
+  load_srow<KIND, NL>(ck_next, ck_rows + (long)ck_index(0) * L.SRS, lane, UP);
+  for (int it = 0; it <= geo.NB + 2; ++it) {
+    const int j = it - 1;
+    if (j >= 0 && j < nb) {
+      const int g = geo.absblock(2, SIDE, j);
+      const int nv = geo.nvof(g);
+      const float(*E)[LD::ES] = lds.E[SIDE][j % 3];
+      float(*RR)[LD::RS] = lds.R[SIDE][j % 3];
+      const SRow<KIND, NL> ck = ck_next;
+      load_srow<KIND, NL>(ck_next, ck_rows + (long)ck_index(j + 1) * L.SRS, lane, UP);  // next block's checkpoint, a block ahead
+      restore_state<KIND, NL, RDIR>(S, ck);
+      auto put = [&](int d) __attribute__((always_inline)) {
+        float cs[NL];
+        float4 tail;
+        state_row<KIND, NL, RDIR>(S, cs, tail);
+        write_R<KIND, NL, LD>(RR[d], dump, lane, cs, S.o, tail);
+      };
+      auto stp = [&](int d) __attribute__((always_inline)) {
+        Emis<NL> e;
+        read_E<NL, LD>(E[d], lane, e);
+        S.step(e);
+      };
+      if constexpr (SIDE == 0) {
+        // beta recursion downward: R[nv-1] = beta[BLK g + nv] (the checkpoint), then R[d-1] = beta[BLK g + d] after frame d
+        write_R<KIND, NL, LD>(RR[nv - 1], dump, lane, ck.a, ck.b, ck.tail);
+        if (nv == BLK) {
+#pragma unroll
+          for (int d = BLK - 1; d >= 1; --d) { stp(d); put(d - 1); }
+        } else {
+          for (int d = nv - 1; d >= 1; --d) { stp(d); put(d - 1); }
+        }
+      } else {
+        // alpha recursion upward; B's position d holds frame BLK g + nv-1-d (B-side blocks of phase 2 are always full)
+        if constexpr (KIND == 0) {
+          if (nv == BLK) {
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) { stp(BLK - 1 - i); put(BLK - 1 - i); }
+          } else {
+            for (int i = 0; i < nv; ++i) { stp(nv - 1 - i); put(nv - 1 - i); }
+          }
+        } else {
+          write_R<KIND, NL, LD>(RR[nv - 1], dump, lane, ck.a, ck.b, ck.tail);  // a[BLK g]
+          if (nv == BLK) {
+#pragma unroll
+            for (int i = 1; i < BLK; ++i) { stp(BLK - i); put(BLK - 1 - i); }
+          } else {
+            for (int i = 1; i < nv; ++i) { stp(nv - i); put(nv - 1 - i); }
+          }
+        }
+      }
+    }
+    STAMP(st.mid());
+    block_barrier();
+    STAMP(st.end());
+  }
+  STAMP(st.dump(reinterpret_cast<unsigned long long *>(stamp_ws) + ((long)b * LD::NW + 2 + SIDE) * 4, lane));
+}
+
+// ------------------------------------------------------------------------------------------------
+// helper wavefront h of NH per side: positions d = h, h + NH, ... of every block (FPH = BLK / NH per block)
+// ------------------------------------------------------------------------------------------------
+template <int KIND, int NL, int NH, int BLK, int DIR>
+__device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, float2 *__restrict__ stats_ws,
+                                           const float *__restrict__ d_loss, float *__restrict__ grad,
+                                           Lds<KIND, NL, NH, BLK> &lds, const Geo<BLK> &geo, int h, void *stamp_ws) {
+  constexpr int V = 256;
+  constexpr int FPH = BLK / NH;
+  using S_t = Side<KIND, NL, 1, DIR, true>;
+  using LD = Lds<KIND, NL, NH, BLK>;
+  S_t S;
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x;
+  const int T = p.T;
+  S.lane = lane; S.UP = L.UP; S.blank = p.blank;
+  const int len = geo.len;
+  int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  if (ll > p.U) ll = 0;
+  S.ll = ll;
+  S.xbase = p.logits + (long)b * T * V;
+  S.gbase = grad + (long)b * T * V;
+  S.xs = lds.xcopy[DIR * NH + h];
+  S.bins = lds.bins[DIR * NH + h];
+  S.dl = d_loss ? d_loss[b] : 1.0f;
+  init_labels<KIND, NL, DIR>(S, p, b, lane, ll);
+  if (lane == 0) S.xs[V] = -6.0e29f;  // pad slot of the gather copy: "log 0" for label positions beyond label_length
+  float2 *stats = stats_ws + (long)b * T;
+  float *dump = lds.dump[4 + DIR * NH + h];
+  STAMP(Stamps st; st.begin());
+
+  auto write_E = [&](float *row, const Emis<NL> &e) __attribute__((always_inline)) {
+    float *q = row + lane * NL;
+    if constexpr (NL == 1) q[0] = e.y[0];
+    else *reinterpret_cast<float2 *>(q) = make_float2(e.y[0], e.y[1]);
+    float *tq = (lane == 0) ? row + LD::UP : dump + (lane & 15) * 4;  // lanes >= 16 overlap in the sink: harmless
+    *reinterpret_cast<float4 *>(tq) = make_float4(e.bl, e.mx, e.l2s, 0.f);
+  };
+  // frame at position d of this side's block j of `phase`, clamped into [0, len) so that prefetches past the end are legal
+  auto fr = [&](int phase, int j, int d) -> int {
+    const int nb = geo.nblocks(phase, DIR);
+    int jj = j < nb ? j : nb - 1;
+    jj = jj < 0 ? 0 : jj;
+    const int g = geo.absblock(phase, DIR, jj);
+    const int nv = geo.nvof(g);
+    int dd = d < nv ? d : nv - 1;
+    int t = geo.frame(DIR, g, dd < 0 ? 0 : dd);
+    t = t < len ? t : len - 1;
+    return t < 0 ? 0 : t;
+  };
+
+  // ================= phase 1: E stage with statistics (recorded for the other side's pass over the same frames) =========
+  {
+    const int nb = geo.nblocks(1, DIR);
+    float4 xb[FPH][1];
+    if (nb > 0) static_for<0, FPH>([&](auto Q) { S.load_x(xb[decltype(Q)::value], fr(1, 0, h + NH * decltype(Q)::value)); });
+    for (int it = 0; it <= geo.NB; ++it) {
+      const int j = it;
+      if (j < nb) {
+        const int g = geo.absblock(1, DIR, j);
+        const int nv = geo.nvof(g);
+        float(*E)[LD::ES] = lds.E[DIR][j % 3];
+        float smx = 0.f, sl2 = 0.f;  // lane d keeps the statistics of position d of the block
+        if (nv == BLK) {
+          static_for<0, FPH>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            const int d = h + NH * q;
+            Emis<NL> e;
+            S.emit(xb[q], 0, e);
+            write_E(E[d], e);
+            smx = (lane == d) ? e.mx : smx;
+            sl2 = (lane == d) ? e.l2s : sl2;
+          });
+        } else {
+          for (int d = h; d < nv; d += NH) {
+            float4 xr[1];
+            S.load_x(xr, geo.frame(DIR, g, d));
+            Emis<NL> e;
+            S.emit(xr, 0, e);
+            write_E(E[d], e);
+            smx = (lane == d) ? e.mx : smx;
+            sl2 = (lane == d) ? e.l2s : sl2;
+          }
+        }
+        static_for<0, FPH>([&](auto Q) { S.load_x(xb[decltype(Q)::value], fr(1, j + 1, h + NH * decltype(Q)::value)); });
+        if (lane < nv && (lane % NH) == h) stats[geo.frame(DIR, g, lane)] = make_float2(smx, sl2);
+      }
+      STAMP(st.mid());
+      block_barrier();
+      STAMP(st.end());
+    }
+  }
+
+  STAMP(st.phase1_done());
+  // ================= meeting point =================
+  __syncthreads();
+  __syncthreads();
+  const bool feasible = lds.feasible != 0;
+
+  // ================= phase 2: E stage (statistics from the record), G stage three blocks behind =================
+  {
+    const int nb = geo.nblocks(2, DIR);
+    if (h == 0) {
+      if (!feasible) {  // zero gradient for the whole sample (base_loss.py:283-288); barrier schedule unchanged
+        if constexpr (DIR == 0) S.zero_rows(geo.tm, T); else S.zero_rows(0, geo.tm);
+      } else if (DIR == 0) {
+        S.zero_rows(len, T);  // padded frames (base_loss.py:291-296)
+      }
+    }
+    float4 xb[FPH][1];
+    float4 xg1[FPH][1], xg2[FPH][1], xg3[FPH][1];  // logits rows of the three previous blocks (G stage)
+    static_for<0, FPH>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      xg1[q][0] = make_float4(0.f, 0.f, 0.f, 0.f); xg2[q][0] = xg1[q][0]; xg3[q][0] = xg1[q][0];
+    });
+    float2 st_cur = make_float2(0.f, 0.f), st_next = make_float2(0.f, 0.f);
+    float2 sg1 = st_cur, sg2 = st_cur, sg3 = st_cur;  // the statistics travel with the rows
+    if (nb > 0) {
+      static_for<0, FPH>([&](auto Q) { S.load_x(xb[decltype(Q)::value], fr(2, 0, h + NH * decltype(Q)::value)); });
+      st_cur = stats[fr(2, 0, lane)];
+    }
+    for (int it = 0; it <= geo.NB + 2; ++it) {
+      // ---- E stage (block it) ----
+      const int j = it;
+      float4 xe[FPH][1];
+      static_for<0, FPH>([&](auto Q) { xe[decltype(Q)::value][0] = xg1[decltype(Q)::value][0]; });
+      float2 se = st_cur;
+#ifdef CTC_DBG_NO_E2
+      if (false) {
+#else
+      if (j < nb) {
+#endif
+        const int g = geo.absblock(2, DIR, j);
+        const int nv = geo.nvof(g);
+        float(*E)[LD::ES] = lds.E[DIR][j % 3];
+        st_next = stats[fr(2, j + 1, lane)];
+        if (nv == BLK) {
+          static_for<0, FPH>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            const int d = h + NH * q;
+            Emis<NL> e;
+            S.gather(xb[q], 0, readlane_f(st_cur.x, d), readlane_f(st_cur.y, d), e);
+            write_E(E[d], e);
+            xe[q][0] = make_float4(xb[q][0].x, xb[q][0].y, xb[q][0].z, xb[q][0].w);
+          });
+        } else {
+          for (int d = h; d < nv; d += NH) {
+            float4 xr[1];
+            S.load_x(xr, geo.frame(DIR, g, d));
+            float2 sd = stats[geo.frame(DIR, g, d)];
+            Emis<NL> e;
+            S.gather(xr, 0, sd.x, sd.y, e);
+            write_E(E[d], e);
+          }
+        }
+        static_for<0, FPH>([&](auto Q) { S.load_x(xb[decltype(Q)::value], fr(2, j + 1, h + NH * decltype(Q)::value)); });
+        st_cur = st_next;
+      }
+      // ---- G stage (block it-3): posterior scatter + gradient rows ----
+      const int gj = it - 3;
+#ifdef CTC_DBG_NO_G
+      if (false) {
+#else
+      if (feasible && gj >= 0 && gj < nb) {
+#endif
+        const int g = geo.absblock(2, DIR, gj);
+        const int nv = geo.nvof(g);
+        const float(*SR)[LD::RS] = lds.R[DIR][gj % 3];
+        auto g_frame = [&](int d, const float4(&xr)[1], float mx, float l2s) __attribute__((always_inline)) {
+          const float *row = SR[d];
+          float s1[NL], s2[NL];
+          const float *q = row + 2 * lane * NL;
+          if constexpr (NL == 1) {
+            float2 v = *reinterpret_cast<const float2 *>(q);
+            s1[0] = v.x; s2[0] = v.y;
+          } else {
+            float4 v = *reinterpret_cast<const float4 *>(q);
+            s1[0] = v.x; s2[0] = v.y; s1[1] = v.z; s2[1] = v.w;
+          }
+          const float s0 = row[2 * LD::UP];
+          Emis<NL> e;
+          e.mx = mx; e.l2s = l2s;
+          S.grad_row(geo.frame(DIR, g, d), s1, s2, s0, xr, e);
+        };
+        if (nv == BLK) {
+          static_for<0, FPH>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            const int d = h + NH * q;
+            g_frame(d, xg3[q], readlane_f(sg3.x, d), readlane_f(sg3.y, d));
+          });
+        } else {
+          for (int d = h; d < nv; d += NH) {
+            float4 xr[1];
+            S.load_x(xr, geo.frame(DIR, g, d));
+            float2 sd = stats[geo.frame(DIR, g, d)];
+            g_frame(d, xr, sd.x, sd.y);
+          }
+        }
+      }
+      static_for<0, FPH>([&](auto Q) {  // rotate the kept rows: it-2 -> it-3, it-1 -> it-2, it -> it-1
+        constexpr int q = decltype(Q)::value;
+        xg3[q][0] = xg2[q][0]; xg2[q][0] = xg1[q][0]; xg1[q][0] = xe[q][0];
+      });
+      sg3 = sg2; sg2 = sg1; sg1 = se;
+      STAMP(st.mid());
+      block_barrier();
+      STAMP(st.end());
+    }
+  }
+  STAMP(st.dump(reinterpret_cast<unsigned long long *>(stamp_ws) + ((long)b * LD::NW + 4 + DIR * NH + h) * 4, lane));
+}
+
+// Wavefront roles: 0 main A, 1 main B, 2 recompute for A, 3 recompute for B, then NH helpers of A, NH helpers of B.
+template <int KIND, int NL, int NH, int BLK>
+__global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused5_kernel(Problem p, Layout L, float *__restrict__ alpha_ws,
+                                                                    float *__restrict__ beta_ws,
+                                                                    double *__restrict__ logp_ws,
+                                                                    float2 *__restrict__ stats_ws,
+                                                                    float *__restrict__ loss,
+                                                                    const float *__restrict__ d_loss,
+                                                                    float *__restrict__ grad, void *stamp_ws) {
+  __shared__ __attribute__((aligned(16))) Lds<KIND, NL, NH, BLK> lds;
+  const int w = threadIdx.x >> 6;
+  Geo<BLK> geo;  // every wavefront derives the same block schedule: the barrier counts match by construction
+  geo.init(clampi(p.logit_length[blockIdx.x], 0, p.T));
+  if (w == 0) {
+    __builtin_amdgcn_s_setprio(3);  // the sequential chains win issue arbitration against co-resident helpers
+    run_main<KIND, NL, NH, BLK, 0>(p, L, alpha_ws, beta_ws, logp_ws, loss, lds, geo, stamp_ws);
+  } else if (w == 1) {
+    __builtin_amdgcn_s_setprio(3);
+    run_main<KIND, NL, NH, BLK, 1>(p, L, alpha_ws, beta_ws, logp_ws, loss, lds, geo, stamp_ws);
+  } else if (w == 2) {
+    __builtin_amdgcn_s_setprio(2);
+    run_recompute<KIND, NL, NH, BLK, 0>(p, L, alpha_ws, beta_ws, lds, geo, stamp_ws);
+  } else if (w == 3) {
+    __builtin_amdgcn_s_setprio(2);
+    run_recompute<KIND, NL, NH, BLK, 1>(p, L, alpha_ws, beta_ws, lds, geo, stamp_ws);
+  } else if (w < 4 + NH) {
+    run_helper<KIND, NL, NH, BLK, 0>(p, L, stats_ws, d_loss, grad, lds, geo, w - 4, stamp_ws);
+  } else {
+    run_helper<KIND, NL, NH, BLK, 1>(p, L, stats_ws, d_loss, grad, lds, geo, w - 4 - NH, stamp_ws);
+  }
+}
+
+}  // namespace fused5
+
+template <int NL>
+static hipError_t launch5(const Problem &p, const Layout &L, float *a, float *b, double *lp, float2 *stats, float *loss,
+                          const float *d_loss, float *grad, void *stamp, hipStream_t st) {
+  constexpr int NH = 4, BLK = 12;
+  hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK>), dim3(p.B), dim3(64 * (4 + 2 * NH)), 0, st, p, L,
+                     a, b, lp, stats, loss, d_loss, grad, stamp);
+  return hipGetLastError();
+}
+
+#if CTC_FUSED_KIND == 0
+hipError_t run_fused5_classic
+#else
+hipError_t run_fused5_simplified
+#endif
+    (const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
+  float *alpha = reinterpret_cast<float *>(ws + L.off_alpha);
+  float *beta = reinterpret_cast<float *>(ws + L.off_beta);
+  double *logp = reinterpret_cast<double *>(ws + L.off_logp);
+  float2 *stats = reinterpret_cast<float2 *>(ws + L.off_emis);  // the emission region of the v1 pipeline is free here
+  void *stamp = ws + L.off_dummy;  // diagnostic builds (-DCTC_FUSED_STAMPS) write per-wavefront cycle counts here
+  switch (L.NL) {
+    case 1: return launch5<1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
+    case 2: return launch5<2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace ctc
