@@ -134,11 +134,11 @@ def main():
 
     def full_step():
         loss = step()
-        s = loss.sum()
+        s = loss.sum()  # the scalar a training loop takes from the loss (README.md:62); all-reduced when N > 1
         if world > 1:
             import torch.distributed as dist
             dist.all_reduce(s)  # the one collective of the path: scalar sum of the losses over RCCL/xGMI
-        total.copy_(s)
+        return s
 
     for _ in range(args.warmup):
         full_step()

@@ -303,13 +303,17 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
         const int nv = geo.nvof(g);
         const float(*E)[LD::ES] = lds.E[DIR][j % 3];
         float(*RR)[LD::RS] = lds.R[DIR][j % 3];
+        // every row of the block carries the offset of the checkpoint it was regenerated from, and this chain
+        // renormalises only at block ends: the posterior scale is a per-block constant
+        const float4 tl0 = *reinterpret_cast<const float4 *>(RR[0] + (KIND == 0 ? 2 : 1) * LD::UP);
+        const float sc = (float)((double)tl0.z + (S.off - dlogp)) + tl0.w;
         auto one = [&](int d) __attribute__((always_inline)) {
           Emis<NL> e;
           read_E<NL, LD>(E[d], lane, e);
           SRow<KIND, NL> r;
           read_R<KIND, NL, LD>(RR[d], lane, r);
           float s1[NL], s2[NL], s0;
-          S.post_step(e, r, dlogp, s1, s2, s0);
+          S.post_step_sc(e, r, sc, s1, s2, s0);
           float *row = RR[d];  // S row in place
           float *q = row + 2 * lane * NL;
           if constexpr (NL == 1) *reinterpret_cast<float2 *>(q) = make_float2(s1[0], s2[0]);
@@ -491,10 +495,25 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
   };
 
   // ================= phase 1: E stage with statistics (recorded for the other side's pass over the same frames) =========
+  // Uneven split: helpers 0 .. NH/2-1 sit on the SIMDs of the two main chains and take LQ positions of each block,
+  // helpers NH/2 .. NH-1 sit on the SIMDs of the recompute chains -- idle in this phase -- and take HQ.
   {
+    static_assert(BLK == 12 && NH == 4, "phase-1 position map is written for BLK = 12, NH = 4");
+    constexpr int LQ = 2, HQ = 4;
+    const bool light = h < NH / 2;
+    const int nq = light ? LQ : HQ;
+    auto pos1 = [&](int q) -> int {  // q-th position of this helper: light {r, r+6}, heavy {r+2, r+4, r+8, r+10}, r = h & 1
+      const int k = light ? 3 * q : 3 * (q >> 1) + 1 + (q & 1);
+      return (h & 1) + 2 * k;
+    };
+    auto owner1 = [&](int d) -> int { return ((d >> 1) % 3 == 0) ? (d & 1) : 2 + (d & 1); };
     const int nb = geo.nblocks(1, DIR);
-    float4 xb[FPH][1];
-    if (nb > 0) static_for<0, FPH>([&](auto Q) { S.load_x(xb[decltype(Q)::value], fr(1, 0, h + NH * decltype(Q)::value)); });
+    float4 xb[HQ][1];
+    static_for<0, HQ>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      xb[q][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (nb > 0 && q < nq) S.load_x(xb[q], fr(1, 0, pos1(q)));
+    });
     for (int it = 0; it <= geo.NB; ++it) {
       const int j = it;
       if (j < nb) {
@@ -503,28 +522,36 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         float(*E)[LD::ES] = lds.E[DIR][j % 3];
         float smx = 0.f, sl2 = 0.f;  // lane d keeps the statistics of position d of the block
         if (nv == BLK) {
-          static_for<0, FPH>([&](auto Q) {
+          static_for<0, HQ>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
-            const int d = h + NH * q;
-            Emis<NL> e;
-            S.emit(xb[q], 0, e);
-            write_E(E[d], e);
-            smx = (lane == d) ? e.mx : smx;
-            sl2 = (lane == d) ? e.l2s : sl2;
+            if (q < nq) {
+              const int d = pos1(q);
+              Emis<NL> e;
+              S.emit(xb[q], 0, e);
+              write_E(E[d], e);
+              smx = (lane == d) ? e.mx : smx;
+              sl2 = (lane == d) ? e.l2s : sl2;
+            }
           });
         } else {
-          for (int d = h; d < nv; d += NH) {
-            float4 xr[1];
-            S.load_x(xr, geo.frame(DIR, g, d));
-            Emis<NL> e;
-            S.emit(xr, 0, e);
-            write_E(E[d], e);
-            smx = (lane == d) ? e.mx : smx;
-            sl2 = (lane == d) ? e.l2s : sl2;
+          for (int q = 0; q < nq; ++q) {
+            const int d = pos1(q);
+            if (d < nv) {
+              float4 xr[1];
+              S.load_x(xr, geo.frame(DIR, g, d));
+              Emis<NL> e;
+              S.emit(xr, 0, e);
+              write_E(E[d], e);
+              smx = (lane == d) ? e.mx : smx;
+              sl2 = (lane == d) ? e.l2s : sl2;
+            }
           }
         }
-        static_for<0, FPH>([&](auto Q) { S.load_x(xb[decltype(Q)::value], fr(1, j + 1, h + NH * decltype(Q)::value)); });
-        if (lane < nv && (lane % NH) == h) stats[geo.frame(DIR, g, lane)] = make_float2(smx, sl2);
+        static_for<0, HQ>([&](auto Q) {
+          constexpr int q = decltype(Q)::value;
+          if (q < nq) S.load_x(xb[q], fr(1, j + 1, pos1(q)));
+        });
+        if (lane < nv && owner1(lane) == h) stats[geo.frame(DIR, g, lane)] = make_float2(smx, sl2);
       }
       STAMP(st.mid());
       block_barrier();

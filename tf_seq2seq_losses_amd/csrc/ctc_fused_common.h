@@ -400,8 +400,13 @@ struct Side {
   // posterior exponents of one frame (+ the lattice step at the right place): fills s1 (blank parts), s2 (token parts), s0
   __device__ __forceinline__ void post_step(const Emis<NL> &e, const SRow<KIND, NL> &r, double dlogp, float (&s1)[NL],
                                             float (&s2)[NL], float &s0) {
+    post_step_sc(e, r, (float)((double)r.tail.z + (off - dlogp)) + r.tail.w, s1, s2, s0);
+  }
+  // same with the scale sc = off + row offset - log2 P supplied by the caller (constant inside a block when neither this
+  // chain nor the producer of the rows renormalises inside the block)
+  __device__ __forceinline__ void post_step_sc(const Emis<NL> &e, const SRow<KIND, NL> &r, float sc, float (&s1)[NL],
+                                               float (&s2)[NL], float &s0) {
     if constexpr (KIND == 0 && DIR == 0) step(e);
-    const float sc = (float)((double)r.tail.z + (off - dlogp)) + r.tail.w;
     if constexpr (KIND == 0) {
 #pragma unroll
       for (int j = 0; j < NL; ++j) { s1[j] = c[j] + r.a[j] + sc; s2[j] = o[j] + r.b[j] + sc; }
