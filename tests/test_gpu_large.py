@@ -77,7 +77,10 @@ def test_hessian_config_properties(kind):
     loss, grad, h = ops.hessian(ops.KINDS[kind], _lib.WRT_LOGITS, p)
     hs = h.reshape(B, T * V, T * V)
     assert torch.isfinite(hs).all()
-    assert (hs - hs.transpose(1, 2)).abs().max().item() < 1e-5          # symmetry (tests/test_hessian.py:89-108)
+    # symmetry (tests/test_hessian.py:89-108).  The two triangles are generated independently (forward / backward
+    # propagation), so they agree to float32 rounding of the T = 200 recursions, not bit for bit like the reference's
+    # explicit symmetrisation; the reference's own tolerance (6 places at T = 4) is asserted in test_gpu_parity.py.
+    assert (hs - hs.transpose(1, 2)).abs().max().item() < 1e-4
     assert h.sum(dim=4).abs().max().item() < 1e-4                       # softmax gauge: sum_j H[t1,i,t2,j] = 0 per frame t2
     assert h[1, 150:].abs().max().item() == 0 and h[1, :, :, 150:].abs().max().item() == 0
     # Hessian-vector product against central finite differences of the HIP gradient (tests/finite_difference.py)

@@ -192,6 +192,20 @@ def test_autograd_first_and_second_order(kind):
         torch.autograd.grad(hv.sum(), x)
 
 
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_hessian_symmetry_reference_size(kind):
+    """tests/test_hessian.py:89-108 : the log-probability-space Hessian is symmetric under (t1,k1) <-> (t2,k2);
+    asserted like the reference does: |exp(H^T) - exp(H)|_inf at 6 places, B=1, T=4, V=3."""
+    import tf_seq2seq_losses_amd as ctc
+    inp = O.generate_ctc_loss_inputs(1, 4, 0, 3)
+    inp["logit_length"][:] = 4
+    inp["label_length"][:] = 1
+    cls = ctc.ClassicCtcLossData if kind == "classic" else ctc.SimplifiedCtcLossData
+    lp = torch.log_softmax(_t(inp["logits"]), dim=2)
+    h = cls(_t(inp["labels"]), lp, _t(inp["label_length"]), _t(inp["logit_length"]), 0).hessian
+    assert (torch.exp(h.permute(0, 3, 4, 1, 2)) - torch.exp(h)).abs().max().item() < 0.5e-6
+
+
 def test_input_validation_matches_reference():
     """base_loss.py:129-138 : AssertionError on rank / dtype / batch mismatch."""
     import tf_seq2seq_losses_amd as ctc

@@ -390,8 +390,11 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
     return;
   }
   int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  // posterior scatter with fixed-point integer LDS atomics (2^-30 resolution; ds_add_f32 is far slower on gfx950)
   float *bin = lds + (long)w * V;
-  for (int k = lane; k < V; k += 64) bin[k] = 0.f;
+  unsigned *ubin = reinterpret_cast<unsigned *>(bin);
+  auto tofix = [](float q) -> unsigned { return (unsigned)(fminf(q, 1.0f) * 1073741824.0f + 0.5f); };
+  for (int k = lane; k < V; k += 64) ubin[k] = 0u;
   __builtin_amdgcn_wave_barrier();
 
   const int32_t *lab = p.labels + (long)b * p.label_stride;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
       if (i < ll) {
         float q = post(a.y, bb.y);
         int tok = (i < p.label_stride) ? lab[i] : p.blank;
-        if (tok >= 0 && tok < V && tok != p.blank) atomicAdd(&bin[tok], q);
+        if (tok >= 0 && tok < V && tok != p.blank) atomicAdd(&ubin[tok], tofix(q));
       }
     }
     if (lane == 0) qblank += post(ra[2 * UP], rb[2 * UP]);
@@ -426,13 +429,15 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
         float aprev = (i == 0) ? ra[UP] : ra[i - 1];  // a[t, l = i]
         float q = post3(aprev, er[i], bi);  // a[t, l=i] * y[t,i] * b[t+1, l=i+1]
         int tok = (i < p.label_stride) ? lab[i] : p.blank;
-        if (tok >= 0 && tok < V && tok != p.blank) atomicAdd(&bin[tok], q);
+        if (tok >= 0 && tok < V && tok != p.blank) atomicAdd(&ubin[tok], tofix(q));
       }
     }
     if (lane == 0) qblank += post3(ra[UP], rb[UP], bl);
   }
   qblank = wave_sum(qblank);
-  if (lane == 0 && p.blank >= 0 && p.blank < V) bin[p.blank] = qblank;
+  if (lane == 0 && p.blank >= 0 && p.blank < V) ubin[p.blank] = tofix(qblank);
+  __builtin_amdgcn_wave_barrier();
+  for (int k = lane; k < V; k += 64) bin[k] = (float)ubin[k] * 9.31322574615478515625e-10f;  // back to float, in place
   __builtin_amdgcn_wave_barrier();
 
   const float dl = d_loss ? d_loss[b] : 1.0f;
