@@ -63,6 +63,10 @@ int ctc_amd_abi_version(void);
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char *ctc_amd_last_error(void);
 
+/* Name of the kernel pipeline ctc_amd_loss_grad would run for these shapes ("fused5", "fused4", "fused2" or "v1");
+ * diagnostic only (benchmarks and tests report it), never needed for correctness. */
+const char *ctc_amd_pipeline_name(int kind, int wrt, int B, int T, int V, int U, int want_grad);
+
 /* Bytes of device workspace the call selected by `what` needs for these shapes. */
 int ctc_amd_workspace_bytes(int what, int kind, int B, int T, int V, int U, size_t *out_bytes /*host*/);
 

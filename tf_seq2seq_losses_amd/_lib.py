@@ -29,6 +29,7 @@ _COMMON = [_c_int, _c_int,            # kind, wrt
 SIGNATURES = {
     "ctc_amd_abi_version": (_c_int, []),
     "ctc_amd_last_error": (ctypes.c_char_p, []),
+    "ctc_amd_pipeline_name": (ctypes.c_char_p, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "ctc_amd_workspace_bytes": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_size_t)]),
     "ctc_amd_loss_grad": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "ctc_amd_alpha_beta": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
@@ -71,6 +72,10 @@ def check(rc: int, what: str) -> None:
     if rc == EINVAL:
         raise ValueError(f"{what}: {msg}")
     raise CtcAmdError(f"{what} failed with code {rc}: {msg}")
+
+
+def pipeline_name(kind: int, wrt: int, B: int, T: int, V: int, U: int, want_grad: bool = True) -> str:
+    return load().ctc_amd_pipeline_name(kind, wrt, B, T, V, U, int(want_grad)).decode()
 
 
 def workspace_bytes(what: int, kind: int, B: int, T: int, V: int, U: int) -> int:

@@ -88,6 +88,29 @@ int ctc_amd_abi_version(void) { return CTC_AMD_ABI_VERSION; }
 
 const char *ctc_amd_last_error(void) { return g_err; }
 
+static const char *select_pipeline(const ctc::Problem &p, const ctc::Layout &L, bool want_grad) {
+  // pipeline selection by shape eligibility: fused5 (ctc_fused5.hip: chains + recompute chains + helpers, no lattice
+  // spill) > fused4 (ctc_fused4.hip: chains + helpers, half of the lattice spilled) > fused2 (ctc_fused.hip: two
+  // self-contained wavefronts) > v1 (emit -> scan -> grad).  CTC_AMD_PIPELINE=v1|fused2|fused4 forces a lower tier
+  // (the parity tests run all of them).
+  const char *pipe = getenv("CTC_AMD_PIPELINE");
+  const bool force_v1 = pipe && pipe[0] == 'v' && pipe[1] == '1';
+  const bool force_f2 = pipe && pipe[0] == 'f' && pipe[5] == '2';
+  const bool force_f4 = pipe && pipe[0] == 'f' && pipe[5] == '4';
+  if (!want_grad || force_v1) return "v1";
+  if (!force_f2 && !force_f4 && ctc::fused5_eligible(p, L)) return "fused5";
+  if (!force_f2 && ctc::fused4_eligible(p, L)) return "fused4";
+  if (ctc::fused_eligible(p, L)) return "fused2";
+  return "v1";
+}
+
+const char *ctc_amd_pipeline_name(int kind, int wrt, int B, int T, int V, int U, int want_grad) {
+  if ((kind != 0 && kind != 1) || B < 0 || T < 0 || V <= 0 || U < 0 || U > MAX_U) return "invalid";
+  ctc::Layout L = ctc::make_layout(kind, B, T, U, 0);
+  ctc::Problem p = make_problem(kind, wrt, nullptr, nullptr, 0, nullptr, nullptr, 0, B, T, V, U);
+  return select_pipeline(p, L, want_grad != 0);
+}
+
 int ctc_amd_workspace_bytes(int what, int kind, int B, int T, int V, int U, size_t *out_bytes) {
   if (!out_bytes) return fail(CTC_AMD_EINVAL, "out_bytes is null");
   if (kind != 0 && kind != 1) return fail(CTC_AMD_EINVAL, "bad kind %d", kind);
@@ -112,27 +135,13 @@ int ctc_amd_loss_grad(int kind, int wrt, const float *logits, const int32_t *lab
   if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
   ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // pipeline selection by shape eligibility: fused5 (ctc_fused5.hip: chains + recompute chains + helpers, no lattice
-  // spill) > fused4 (ctc_fused4.hip: chains + helpers, half of the lattice spilled) > fused2 (ctc_fused.hip: two
-  // self-contained wavefronts) > v1 (emit -> scan -> grad).  CTC_AMD_PIPELINE=v1|fused2|fused4 forces a lower tier
-  // (the parity tests run all of them).
-  const char *pipe = getenv("CTC_AMD_PIPELINE");
-  const bool force_v1 = pipe && pipe[0] == 'v' && pipe[1] == '1';
-  const bool force_f2 = pipe && pipe[0] == 'f' && pipe[5] == '2';
-  const bool force_f4 = pipe && pipe[0] == 'f' && pipe[5] == '4';
-  if (grad && !force_v1 && !force_f2 && !force_f4 && ctc::fused5_eligible(p, L)) {
-    hipError_t ef = ctc::run_fused5(p, L, static_cast<char *>(workspace), loss, d_loss, grad, st);
-    if (ef != hipSuccess) return hip_fail(ef, "fused5 launch");
-    return CTC_AMD_OK;
-  }
-  if (grad && !force_v1 && !force_f2 && ctc::fused4_eligible(p, L)) {
-    hipError_t ef = ctc::run_fused4(p, L, static_cast<char *>(workspace), loss, d_loss, grad, st);
-    if (ef != hipSuccess) return hip_fail(ef, "fused4 launch");
-    return CTC_AMD_OK;
-  }
-  if (grad && !force_v1 && ctc::fused_eligible(p, L)) {
-    hipError_t ef = ctc::run_fused(p, L, static_cast<char *>(workspace), loss, d_loss, grad, st);
-    if (ef != hipSuccess) return hip_fail(ef, "fused launch");
+  const char *pl = select_pipeline(p, L, grad != nullptr);
+  if (pl[0] == 'f') {
+    char *wsb = static_cast<char *>(workspace);
+    hipError_t ef = (pl[5] == '5') ? ctc::run_fused5(p, L, wsb, loss, d_loss, grad, st)
+                  : (pl[5] == '4') ? ctc::run_fused4(p, L, wsb, loss, d_loss, grad, st)
+                                   : ctc::run_fused(p, L, wsb, loss, d_loss, grad, st);
+    if (ef != hipSuccess) return hip_fail(ef, pl);
     return CTC_AMD_OK;
   }
   hipError_t e = ctc::run_emit_scan(p, L, static_cast<char *>(workspace), loss, grad ? 2 : 1, st);
