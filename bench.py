@@ -125,10 +125,17 @@ def main():
             return loss
         alg_bytes = B * ((T * V) ** 2 * 4 + T * V * 4)
     else:
+        # outputs and workspace are allocated once (the C ABI never allocates); one step = one ctc_amd_loss_grad call
         ws = torch.empty(_lib.workspace_bytes(_lib.WS_LOSS_GRAD, kind, B, T, V, U), dtype=torch.uint8, device=device)
+        loss = torch.empty(B, dtype=torch.float32, device=device)
+        grad = torch.empty((B, T, V), dtype=torch.float32, device=device)
+        lib = _lib.load()
+        args_c = prep.common(kind, _lib.WRT_LOGITS) + (loss.data_ptr(), grad.data_ptr(), None, ws.data_ptr(), ws.numel())
 
         def step():
-            loss, grad = ops.loss_grad(kind, _lib.WRT_LOGITS, prep, want_grad=True, workspace=ws)
+            rc = lib.ctc_amd_loss_grad(*args_c, torch.cuda.current_stream().cuda_stream)
+            if rc:
+                _lib.check(rc, "ctc_amd_loss_grad")
             return loss
         alg_bytes = B * 2 * T * V * 4
 

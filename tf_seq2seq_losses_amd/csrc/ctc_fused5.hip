@@ -313,13 +313,14 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
           SRow<KIND, NL> r;
           read_R<KIND, NL, LD>(RR[d], lane, r);
           float s1[NL], s2[NL], s0;
-          S.post_step_sc(e, r, sc, s1, s2, s0);
+          S.post_step_sc(e, r, 0.f, s1, s2, s0);  // exponents WITHOUT the scale: the G stage adds it (off the chain)
           float *row = RR[d];  // S row in place
           float *q = row + 2 * lane * NL;
           if constexpr (NL == 1) *reinterpret_cast<float2 *>(q) = make_float2(s1[0], s2[0]);
           else *reinterpret_cast<float4 *>(q) = make_float4(s1[0], s2[0], s1[1], s2[1]);
           float *tq = (lane == 0) ? row + 2 * LD::UP : dump + lane;
-          *tq = s0;
+          *reinterpret_cast<float2 *>((lane == 0) ? row + 2 * LD::UP : dump + (lane & 31) * 2) = make_float2(s0, sc);
+          (void)tq;
         };
         if (nv == BLK) {
 #pragma unroll
@@ -645,7 +646,10 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
             float4 v = *reinterpret_cast<const float4 *>(q);
             s1[0] = v.x; s2[0] = v.y; s1[1] = v.z; s2[1] = v.w;
           }
-          const float s0 = row[2 * LD::UP];
+          const float2 t0 = *reinterpret_cast<const float2 *>(row + 2 * LD::UP);  // (s0, posterior scale of the block)
+#pragma unroll
+          for (int jj = 0; jj < NL; ++jj) { s1[jj] += t0.y; s2[jj] += t0.y; }
+          const float s0 = t0.x + t0.y;
           Emis<NL> e;
           e.mx = mx; e.l2s = l2s;
           S.grad_row(geo.frame(DIR, g, d), s1, s2, s0, xr, e);
