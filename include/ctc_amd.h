@@ -56,6 +56,7 @@ extern "C" {
 #define CTC_AMD_WS_LOSS_GRAD 0
 #define CTC_AMD_WS_ALPHA_BETA 1
 #define CTC_AMD_WS_HESSIAN 2
+#define CTC_AMD_WS_HVP 3
 
 /* ABI version of the loaded library (== CTC_AMD_ABI_VERSION of the header it was built from). */
 int ctc_amd_abi_version(void);
@@ -113,6 +114,23 @@ int ctc_amd_hessian(int kind, int wrt,
                     int B, int T, int V, int U,
                     float *loss, float *grad, float *hess,
                     void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Hessian-vector product  out[b,t,k] = sum_{t2,k2} H[b,t,k,t2,k2] * vec[b,t2,k2]  without materialising H
+ * (H as ctc_amd_hessian would fill it for the same `wrt`).  O(T*U) memory and work per utterance (tangent-mode
+ * alpha/beta recursion), so it works at sizes where the [B,T,V,T,V] tensor does not fit.
+ * Replaces: gradient_fn.backprop (base_loss.py:157-175), i.e. the contraction the reference performs with a
+ * materialised Hessian when the gradient is differentiated once more (README.md:58-71).
+ *   vec, out  [B,T,V] float   (H is symmetric, so this is also vec^T H)
+ *   loss      [B] (out), grad [B,T,V] (out, NULL to skip): as ctc_amd_hessian
+ * Workspace: CTC_AMD_WS_HVP.
+ */
+int ctc_amd_hvp(int kind, int wrt,
+                const float *logits, const int32_t *labels, int label_stride,
+                const int32_t *label_length, const int32_t *logit_length, int blank_index,
+                int B, int T, int V, int U,
+                const float *vec, float *loss, float *grad, float *out,
+                void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

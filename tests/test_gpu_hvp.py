@@ -1,0 +1,175 @@
+"""Hessian-vector products (ctc_amd_hvp, tangent-mode alpha/beta) against the materialised Hessian.
+
+The reference obtains the second-order product by contracting its [B,T,V,T,V] Hessian inside gradient_fn.backprop
+(base_loss.py:157-175); these tests check that the tangent-mode kernel gives the same numbers as
+  * einsum(oracle Hessian, v)            (NumPy restatement of base_loss.py:186-260 / README.md:58-71), small sizes,
+  * einsum(GPU dense Hessian, v)         (ctc_amd_hessian), sizes across the lane tilings,
+  * central differences of the gradient  at the north-star size, where no Hessian fits in memory,
+and that autograd's double backward takes this route.  Tolerance 1e-4 (relative to max|Hv|, floor 1), float32.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as C
+from oracle import ctc_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(_dev())
+
+
+def _prep(inp, blank=0):
+    from tf_seq2seq_losses_amd import ops
+    return ops.Prepared(_t(inp["labels"]), _t(inp["logits"]), _t(inp["label_length"]), _t(inp["logit_length"]), blank)
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+def _fd64(kind, inp, v, eps):
+    """Central differences of the float64 C-oracle gradient.  The perturbed logits are rounded to float32 first and the
+    direction actually taken, (x+ - x-) / 2 eps, is returned with the quotient, so rounding adds no error."""
+    xp = (inp["logits"].astype(np.float64) + eps * v).astype(np.float32)
+    xm = (inp["logits"].astype(np.float64) - eps * v).astype(np.float32)
+    veff = (xp.astype(np.float64) - xm.astype(np.float64)) / (2 * eps)
+    gp = C.loss_grad(kind, inp["labels"], xp, inp["label_length"], inp["logit_length"], 0)[1]
+    gm = C.loss_grad(kind, inp["labels"], xm, inp["label_length"], inp["logit_length"], 0)[1]
+    return (gp - gm) / (2 * eps), veff.astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+@pytest.mark.parametrize("B,T,V,seed", [(8, 20, 8, 0), (3, 12, 5, 2), (2, 4, 2, 3), (5, 33, 7, 4)])
+def test_hvp_matches_oracle_hessian(kind, B, T, V, seed):
+    from tf_seq2seq_losses_amd import ops, _lib
+    inp = O.generate_ctc_loss_inputs(B, T, seed, V)
+    rng = np.random.default_rng(100 + seed)
+    v = rng.standard_normal((B, T, V)).astype(np.float32)
+    # logits space: README.md:58-71
+    ref = O.ctc_loss(kind, inp["labels"], inp["logits"], inp["label_length"], inp["logit_length"], 0)
+    want = np.einsum("btkuj,buj->btk", O.logits_hessian(ref, inp["logits"]), v.astype(np.float64))
+    loss, grad, out = ops.hvp(ops.KINDS[kind], _lib.WRT_LOGITS, _prep(inp), _t(v), want_grad=True)
+    assert _rel(out.cpu().numpy(), want) < TOL
+    assert np.abs(grad.cpu().numpy() - O.logits_gradient(ref, inp["logits"])).max() < TOL
+    fin = np.isfinite(ref.loss)
+    assert np.array_equal(np.isfinite(loss.cpu().numpy()), fin)
+    # log-probability space: loss_data.hessian, base_loss.py:186-260
+    import tf_seq2seq_losses_amd as ctc
+    lp = torch.log_softmax(_t(inp["logits"]), dim=2)
+    cls = ctc.ClassicCtcLossData if kind == "classic" else ctc.SimplifiedCtcLossData
+    data = cls(_t(inp["labels"]), lp, _t(inp["label_length"]), _t(inp["logit_length"]), 0)
+    refd = O.LOSS_DATA[kind](inp["labels"], lp.cpu().numpy(), inp["label_length"], inp["logit_length"], 0)
+    want_lp = np.einsum("btkuj,buj->btk", refd.hessian, v.astype(np.float64))
+    assert _rel(data.hessian_vector_product(_t(v)).cpu().numpy(), want_lp) < TOL
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+@pytest.mark.parametrize("T,V,U", [(40, 12, 17), (150, 9, 70), (200, 6, 130), (300, 4, 260)])
+def test_hvp_across_lane_tilings(kind, T, V, U):
+    """NL = 1, 2, 4, 8 label positions per lane, repeats, ragged lengths, one empty label, one infeasible sample.
+    Checked against float64 central differences of the C oracle's gradient (2e-4: the differences themselves carry
+    ~4e-5 of truncation) and, loosely (1e-3), against the contraction of the float32 dense Hessian kernel, whose own
+    error at T = 200 is ~5e-4 (it sums T*V float32 entries of g (x) g - P12 per output)."""
+    from tf_seq2seq_losses_amd import ops, _lib
+    inp = O.generate_ctc_loss_inputs(4, T, U, V, max_label_length=U)
+    inp["labels"][0, : U // 2] = 1
+    inp["label_length"][1] = 0
+    inp["logit_length"][2] = max(1, int(inp["label_length"][2]) - 1)  # shorter than the label: infeasible
+    rng = np.random.default_rng(U)
+    fd, v = _fd64(kind, inp, rng.standard_normal((4, T, V)), 1e-3)
+    feas = [0, 1, 3]
+    p = _prep(inp)
+    loss, _, out = ops.hvp(ops.KINDS[kind], _lib.WRT_LOGITS, p, _t(v))
+    outn = out.cpu().numpy()
+    assert np.isfinite(outn).all()
+    assert _rel(outn[feas], fd[feas]) < 2e-4, _rel(outn[feas], fd[feas])
+    assert loss[2].item() == float("inf") and np.all(outn[2] == 0)
+    assert np.all(outn[0, int(inp["logit_length"][0]):] == 0)
+    for wrt in (_lib.WRT_LOGITS, _lib.WRT_LOGPROBS):
+        if wrt == _lib.WRT_LOGPROBS:
+            p = ops.Prepared(_t(inp["labels"]), torch.log_softmax(_t(inp["logits"]), 2), _t(inp["label_length"]),
+                             _t(inp["logit_length"]), 0)
+            out = ops.hvp(ops.KINDS[kind], wrt, p, _t(v))[2]
+        _, _, hess = ops.hessian(ops.KINDS[kind], wrt, p, want_grad=False)
+        want = torch.einsum("btkuj,buj->btk", hess.double(), _t(v).double()).cpu().numpy()
+        del hess
+        assert _rel(out.cpu().numpy(), want) < 1e-3, (wrt, _rel(out.cpu().numpy(), want))
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_hvp_nonzero_blank_and_symmetry(kind):
+    from tf_seq2seq_losses_amd import ops, _lib
+    rng = np.random.default_rng(5)
+    B, T, V, U = 3, 30, 11, 9
+    inp = dict(logits=rng.standard_normal((B, T, V)).astype(np.float32) * 3,
+               labels=rng.integers(0, V - 1, (B, U)).astype(np.int32),
+               label_length=np.array([9, 4, 7], np.int32), logit_length=np.array([30, 22, 15], np.int32))
+    blank = V - 1
+    u, v = (rng.standard_normal((B, T, V)).astype(np.float32) for _ in range(2))
+    p = _prep(inp, blank)
+    hu = ops.hvp(ops.KINDS[kind], _lib.WRT_LOGITS, p, _t(u))[2].double()
+    hv = ops.hvp(ops.KINDS[kind], _lib.WRT_LOGITS, p, _t(v))[2].double()
+    a, b = (_t(v).double() * hu).sum((1, 2)), (_t(u).double() * hv).sum((1, 2))
+    assert ((a - b).abs() / (1 + a.abs())).max().item() < TOL          # <v, Hu> = <u, Hv>
+    assert hv.sum(2).abs().max().item() < TOL                          # logits-space rows sum to zero (softmax gauge)
+    _, _, hess = ops.hessian(ops.KINDS[kind], _lib.WRT_LOGITS, p, want_grad=False)
+    want = torch.einsum("btkuj,buj->btk", hess.double(), _t(v).double())
+    assert ((hv - want).abs().max() / max(1.0, want.abs().max().item())).item() < TOL
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_autograd_second_order_uses_hvp(kind, monkeypatch):
+    """README.md:58-71 route: grad of <gradient, v>; the materialised route (CTC_AMD_HVP=dense) must agree."""
+    import tf_seq2seq_losses_amd as ctc
+    inp = O.generate_ctc_loss_inputs(4, 24, 7, 6)
+    fn = ctc.classic_ctc_loss if kind == "classic" else ctc.simplified_ctc_loss
+    v = _t(np.random.default_rng(3).standard_normal(inp["logits"].shape).astype(np.float32))
+
+    def second(weights):
+        x = _t(inp["logits"]).requires_grad_(True)
+        loss = fn(_t(inp["labels"]), x, _t(inp["label_length"]), _t(inp["logit_length"]), 0)
+        fin = torch.isfinite(loss)
+        (g,) = torch.autograd.grad((loss[fin] * weights[fin]).sum(), x, create_graph=True)
+        (h,) = torch.autograd.grad((g * v).sum(), x)
+        return h
+
+    wts = _t(np.array([1.0, 2.0, -0.5, 3.0], np.float32))
+    fast = second(wts)
+    monkeypatch.setenv("CTC_AMD_HVP", "dense")
+    dense = second(wts)
+    assert torch.isfinite(fast).all()
+    assert ((fast - dense).abs().max() / max(1.0, dense.abs().max().item())).item() < TOL
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_hvp_north_star_size_finite_differences(kind):
+    """B=4 of the north-star shape (T=1000, U=128, V=256): the dense Hessian would need 262 GB per utterance, so the
+    check is against float64 central differences of the C oracle's gradient (truncation ~1e-4 of max|Hv|; the kernel
+    measured 2.7e-4 on MI355X).  Bound: 1e-3 of max|Hv| per utterance."""
+    from tf_seq2seq_losses_amd import ops, _lib
+    B, T, U, V = 4, 1000, 128, 256
+    rng = np.random.default_rng(11)
+    inp = dict(logits=rng.standard_normal((B, T, V)).astype(np.float32),
+               labels=rng.integers(1, V, (B, U)).astype(np.int32),
+               label_length=np.array([128, 100, 64, 128], np.int32), logit_length=np.array([1000, 900, 1000, 517], np.int32))
+    fd, v = _fd64(kind, inp, rng.standard_normal((B, T, V)), 1e-3)
+    out = ops.hvp(ops.KINDS[kind], _lib.WRT_LOGITS, _prep(inp), _t(v))[2]
+    assert torch.isfinite(out).all()
+    outn = out.cpu().numpy().astype(np.float64)
+    for b in range(B):
+        assert np.abs(outn[b] - fd[b]).max() < 1e-3 * np.abs(fd[b]).max(), b
+        assert np.all(outn[b, int(inp["logit_length"][b]):] == 0)
+    # <u, Hv> = <v, Hu> at this size (256k-term inner products: compared on the scale |v| |Hu|)
+    u = rng.standard_normal((B, T, V)).astype(np.float32)
+    hu = ops.hvp(ops.KINDS[kind], _lib.WRT_LOGITS, _prep(inp), _t(u))[2].double()
+    a, b_ = (_t(v).double() * hu).sum((1, 2)), (_t(u).double() * out.double()).sum((1, 2))
+    scale = _t(v).double().flatten(1).norm(dim=1) * hu.flatten(1).norm(dim=1)
+    assert ((a - b_).abs() / scale).max().item() < 1e-4

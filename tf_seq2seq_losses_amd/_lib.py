@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CTC_AMD_LIB", os.path.join(_HERE, "libctc_amd.so"))  
 ABI_VERSION = 1
 CLASSIC, SIMPLIFIED = 0, 1
 WRT_LOGITS, WRT_LOGPROBS = 0, 1
-WS_LOSS_GRAD, WS_ALPHA_BETA, WS_HESSIAN = 0, 1, 2
+WS_LOSS_GRAD, WS_ALPHA_BETA, WS_HESSIAN, WS_HVP = 0, 1, 2, 3
 OK, EINVAL, EWORKSPACE, EHIP = 0, -1, -2, -3
 
 _c_int, _c_void_p, _c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
@@ -34,6 +34,7 @@ SIGNATURES = {
     "ctc_amd_loss_grad": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "ctc_amd_alpha_beta": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "ctc_amd_hessian": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "ctc_amd_hvp": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
 }
 
 _lib = None

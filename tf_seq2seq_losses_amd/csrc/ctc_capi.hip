@@ -39,6 +39,8 @@ inline hipError_t run_fused(const Problem &p, const Layout &L, char *ws, float *
 }
 size_t hessian_extra_bytes(int kind, int B, int T, int V, int U);
 hipError_t run_hessian(const Problem &p, const Layout &L, char *ws, const float *grad, float *hess, hipStream_t st);
+size_t hvp_extra_bytes(int kind, int B, int T, int V, int U);
+hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec, float *out, hipStream_t st);
 }  // namespace ctc
 
 namespace {
@@ -117,6 +119,7 @@ int ctc_amd_workspace_bytes(int what, int kind, int B, int T, int V, int U, size
   if (B < 0 || T < 0 || V <= 0 || U < 0 || U > MAX_U) return fail(CTC_AMD_EINVAL, "bad shape B=%d T=%d V=%d U=%d", B, T, V, U);
   size_t extra = 0;
   if (what == CTC_AMD_WS_HESSIAN) extra = ctc::hessian_extra_bytes(kind, B, T, V, U);
+  else if (what == CTC_AMD_WS_HVP) extra = ctc::hvp_extra_bytes(kind, B, T, V, U);
   else if (what != CTC_AMD_WS_LOSS_GRAD && what != CTC_AMD_WS_ALPHA_BETA) return fail(CTC_AMD_EINVAL, "bad workspace selector %d", what);
   *out_bytes = ctc::make_layout(kind, B, T, U, extra).total;
   return CTC_AMD_OK;
@@ -201,6 +204,31 @@ int ctc_amd_hessian(int kind, int wrt, const float *logits, const int32_t *label
   }
   e = ctc::run_hessian(p, L, ws, g_lp, hess, st);
   if (e != hipSuccess) return hip_fail(e, "hessian launch");
+  return CTC_AMD_OK;
+}
+
+int ctc_amd_hvp(int kind, int wrt, const float *logits, const int32_t *labels, int label_stride,
+                const int32_t *label_length, const int32_t *logit_length, int blank_index, int B, int T, int V, int U,
+                const float *vec, float *loss, float *grad, float *out, void *workspace, size_t workspace_bytes,
+                void *stream) {
+  int rc = check_common(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
+  if (rc) return rc;
+  if (B == 0) return CTC_AMD_OK;
+  if (!loss || !out || (T > 0 && !vec)) return fail(CTC_AMD_EINVAL, "null vec/output pointer");
+  if (V > MAX_V_GRAD) return fail(CTC_AMD_EINVAL, "V=%d exceeds the supported maximum %d", V, MAX_V_GRAD);
+  ctc::Layout L = ctc::make_layout(kind, B, T, U, ctc::hvp_extra_bytes(kind, B, T, V, U));
+  if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
+  ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char *ws = static_cast<char *>(workspace);
+  hipError_t e = ctc::run_emit_scan(p, L, ws, loss, 2, st);
+  if (e != hipSuccess) return hip_fail(e, "emit/scan launch");
+  if (grad) {
+    e = ctc::run_grad(p, L, ws, nullptr, grad, st);
+    if (e != hipSuccess) return hip_fail(e, "grad launch");
+  }
+  e = ctc::run_hvp(p, L, ws, vec, out, st);
+  if (e != hipSuccess) return hip_fail(e, "hvp launch");
   return CTC_AMD_OK;
 }
 

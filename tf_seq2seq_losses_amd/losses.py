@@ -18,6 +18,7 @@ All arithmetic is done by the HIP kernels behind the C ABI (include/ctc_amd.h); 
 """
 from __future__ import annotations
 
+import os
 from functools import cached_property
 from typing import Union
 
@@ -67,8 +68,12 @@ class _HessianContraction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, v, kind, wrt, prep):
-        _, _, hess = ops.hessian(kind, wrt, prep, want_grad=False)
-        return torch.einsum("btkuj,buj->btk", hess, v)
+        # the reference contracts a materialised [B,T,V,T,V] Hessian here; the tangent-mode kernel (ctc_hvp.hip) gives the
+        # same product in O(T*L) memory.  CTC_AMD_HVP=dense keeps the materialised route (parity tests compare both).
+        if os.environ.get("CTC_AMD_HVP", "") == "dense":
+            _, _, hess = ops.hessian(kind, wrt, prep, want_grad=False)
+            return torch.einsum("btkuj,buj->btk", hess, v)
+        return ops.hvp(kind, wrt, prep, v)[2]
 
     @staticmethod
     def backward(ctx, *grads):
@@ -231,6 +236,11 @@ class BaseCtcLossData:
     def hessian(self) -> torch.Tensor:
         """[batch, T, V, T, V]: second derivative w.r.t. log-probabilities (base_loss.py:186-260)"""
         return ops.hessian(self._kind, _lib.WRT_LOGPROBS, self._prep(), want_grad=False)[2]
+
+    def hessian_vector_product(self, vec: TensorLike) -> torch.Tensor:
+        """sum_{t2,k2} hessian[b,t,k,t2,k2] vec[b,t2,k2] without building `hessian` (extension: tangent-mode
+        alpha/beta, ctc_amd_hvp); equals torch.einsum("btkuj,buj->btk", self.hessian, vec)."""
+        return ops.hvp(self._kind, _lib.WRT_LOGPROBS, self._prep(), _as_tensor(vec))[2]
 
     @property
     def gamma(self):

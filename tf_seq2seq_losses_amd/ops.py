@@ -105,3 +105,23 @@ def hessian(kind: int, wrt: int, p: Prepared, want_grad: bool = True):
                                  ws.data_ptr(), ws.numel(), _stream(p.device))
     _lib.check(rc, "ctc_amd_hessian")
     return loss, grad, hess
+
+
+def hvp(kind: int, wrt: int, p: Prepared, vec: torch.Tensor, want_grad: bool = False):
+    """out[b,t,k] = sum_{t2,k2} H[b,t,k,t2,k2] vec[b,t2,k2] through ctc_amd_hvp (no [B,T,V,T,V] tensor)."""
+    lib = _lib.load()
+    assert tuple(vec.shape) == (p.B, p.T, p.V), f"vec must be [B,T,V] = {(p.B, p.T, p.V)}, got {tuple(vec.shape)}"
+    vec = vec.to(device=p.device, dtype=torch.float32).contiguous()
+    loss = torch.empty(p.B, dtype=torch.float32, device=p.device)
+    grad = torch.empty((p.B, p.T, p.V), dtype=torch.float32, device=p.device) if want_grad else None
+    out = torch.empty((p.B, p.T, p.V), dtype=torch.float32, device=p.device)
+    if p.B == 0 or p.T == 0:
+        if p.B and not p.T:
+            loss, _ = loss_grad(kind, wrt, p, False)
+        return loss, grad, out
+    ws = _workspace(_lib.WS_HVP, kind, p)
+    with torch.cuda.device(p.device):
+        rc = lib.ctc_amd_hvp(*p.common(kind, wrt), _ptr(vec), _ptr(loss), _ptr(grad), _ptr(out),
+                             ws.data_ptr(), ws.numel(), _stream(p.device))
+    _lib.check(rc, "ctc_amd_hvp")
+    return loss, grad, out
