@@ -8,4 +8,4 @@ mkdir -p scratch
 hipcc $F -fno-honor-nans -DCTC_FUSED_KIND=0 -DCTC_FUSED_STAMPS -c $C/ctc_fused5.hip -o scratch/f4c_stamp.o &
 hipcc $F -fno-honor-nans -DCTC_FUSED_KIND=1 -DCTC_FUSED_STAMPS -c $C/ctc_fused5.hip -o scratch/f4s_stamp.o &
 wait
-hipcc --offload-arch=gfx950 -fPIC -shared $C/_obj/ctc_kernels.o $C/_obj/ctc_fused_classic.o $C/_obj/ctc_fused_simplified.o $C/_obj/ctc_fused4_classic.o $C/_obj/ctc_fused4_simplified.o scratch/f4c_stamp.o scratch/f4s_stamp.o $C/_obj/ctc_hessian.o $C/_obj/ctc_capi.o -o scratch/libctc_stamps.so
+hipcc --offload-arch=gfx950 -fPIC -shared $C/_obj/ctc_kernels.o $C/_obj/ctc_fused_classic.o $C/_obj/ctc_fused_simplified.o $C/_obj/ctc_fused4_classic.o $C/_obj/ctc_fused4_simplified.o scratch/f4c_stamp.o scratch/f4s_stamp.o $C/_obj/ctc_hessian.o $C/_obj/ctc_hvp.o $C/_obj/ctc_capi.o -o scratch/libctc_stamps.so

@@ -8,4 +8,4 @@ mkdir -p scratch
 hipcc $F -fno-honor-nans -DCTC_FUSED_KIND=0 $2 -c $C/ctc_fused5.hip -o scratch/f5c_$1.o &
 hipcc $F -fno-honor-nans -DCTC_FUSED_KIND=1 $2 -c $C/ctc_fused5.hip -o scratch/f5s_$1.o &
 wait
-hipcc --offload-arch=gfx950 -fPIC -shared $C/_obj/ctc_kernels.o $C/_obj/ctc_fused_classic.o $C/_obj/ctc_fused_simplified.o $C/_obj/ctc_fused4_classic.o $C/_obj/ctc_fused4_simplified.o scratch/f5c_$1.o scratch/f5s_$1.o $C/_obj/ctc_hessian.o $C/_obj/ctc_capi.o -o scratch/libctc_$1.so
+hipcc --offload-arch=gfx950 -fPIC -shared $C/_obj/ctc_kernels.o $C/_obj/ctc_fused_classic.o $C/_obj/ctc_fused_simplified.o $C/_obj/ctc_fused4_classic.o $C/_obj/ctc_fused4_simplified.o scratch/f5c_$1.o scratch/f5s_$1.o $C/_obj/ctc_hessian.o $C/_obj/ctc_hvp.o $C/_obj/ctc_capi.o -o scratch/libctc_$1.so
