@@ -249,7 +249,7 @@ __global__ __launch_bounds__(128) void fused_kernel(Problem p, Layout L, float *
   constexpr int V = 256 * VPL;
   __shared__ __attribute__((aligned(16))) float lds_x[2][2 * (V + 4)];
   __shared__ __attribute__((aligned(16))) float lds_bins[2][V + 4];
-  const int w = threadIdx.x >> 6;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps everything derived from it in SGPRs
   if (w == 0)
     run_side<KIND, NL, VPL, 0, LOGITS>(p, L, alpha_ws, beta_ws, logp_ws, loss, d_loss, grad, sink_ws, lds_x[0], lds_bins[0]);
   else

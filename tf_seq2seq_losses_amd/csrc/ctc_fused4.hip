@@ -569,7 +569,7 @@ __global__ __launch_bounds__(64 * (2 + 2 * NH)) void fused4_kernel(Problem p, La
                                                                     const float *__restrict__ d_loss,
                                                                     float *__restrict__ grad, void *stamp_ws) {
   __shared__ __attribute__((aligned(16))) Lds<KIND, NL, VPL, NH> lds;
-  const int w = threadIdx.x >> 6;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps everything derived from it in SGPRs
   // every wavefront derives the same block counts: the barrier schedule is identical by construction
   const int len = clampi(p.logit_length[blockIdx.x], 0, p.T);
   const int tm = len / 2;

@@ -500,14 +500,15 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
   // helpers NH/2 .. NH-1 sit on the SIMDs of the recompute chains -- idle in this phase -- and take HQ.
   {
     static_assert(BLK == 12 && NH == 4, "phase-1 position map is written for BLK = 12, NH = 4");
-    constexpr int LQ = 2, HQ = 4;
+#ifndef CTC_F5_LQ
+#define CTC_F5_LQ 2
+#endif
+    constexpr int LQ = CTC_F5_LQ, HQ = BLK / 2 - LQ;
     const bool light = h < NH / 2;
     const int nq = light ? LQ : HQ;
-    auto pos1 = [&](int q) -> int {  // q-th position of this helper: light {r, r+6}, heavy {r+2, r+4, r+8, r+10}, r = h & 1
-      const int k = light ? 3 * q : 3 * (q >> 1) + 1 + (q & 1);
-      return (h & 1) + 2 * k;
-    };
-    auto owner1 = [&](int d) -> int { return ((d >> 1) % 3 == 0) ? (d & 1) : 2 + (d & 1); };
+    // positions of parity r = h & 1 are r, r+2, .., r+10: the light helper takes the first LQ of them, the heavy one the rest
+    auto pos1 = [&](int q) -> int { return (h & 1) + 2 * (light ? q : LQ + q); };
+    auto owner1 = [&](int d) -> int { return ((d >> 1) < LQ) ? (d & 1) : 2 + (d & 1); };
     const int nb = geo.nblocks(1, DIR);
     float4 xb[HQ][1];
     static_for<0, HQ>([&](auto Q) {
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused5_kernel(Problem p, La
                                                                     const float *__restrict__ d_loss,
                                                                     float *__restrict__ grad, void *stamp_ws) {
   __shared__ __attribute__((aligned(16))) Lds<KIND, NL, NH, BLK> lds;
-  const int w = threadIdx.x >> 6;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps everything derived from it in SGPRs
   Geo<BLK> geo;  // every wavefront derives the same block schedule: the barrier counts match by construction
   geo.init(clampi(p.logit_length[blockIdx.x], 0, p.T));
   if (w == 0) {

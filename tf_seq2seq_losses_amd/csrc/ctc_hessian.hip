@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void hess_slab_kernel(Problem p, Layout L, con
                                                          float *__restrict__ hess, int wpb) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
-  const int w = threadIdx.x >> 6;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps everything derived from it in SGPRs
   const int T = p.T, V = p.V, UP = L.UP;
   const long ntask = (long)p.B * T * V;
   const long task = (long)blockIdx.x * wpb + w;

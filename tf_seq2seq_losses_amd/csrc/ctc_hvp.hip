@@ -48,7 +48,7 @@ size_t hvp_extra_bytes(int kind, int B, int T, int V, int U) {
 __global__ __launch_bounds__(256) void temit_kernel(Problem p, Layout L, const float *__restrict__ emis,
                                                      const float *__restrict__ vec, float *__restrict__ demis) {
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (row >= (long)p.B * p.T) return;
   const int b = (int)(row / p.T), t = (int)(row % p.T);
   const int len = clampi(p.logit_length[b], 0, p.T);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void hvp_out_kernel(Problem p, Layout L, const
                                                        float *__restrict__ out, int wpb) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
-  const int w = threadIdx.x >> 6;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps everything derived from it in SGPRs
   const long row = (long)blockIdx.x * wpb + w;
   if (row >= (long)p.B * p.T) return;
   const int b = (int)(row / p.T), t = (int)(row % p.T);

@@ -23,7 +23,7 @@ __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? l
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void emit_kernel(Problem p, Layout L, float *__restrict__ emis) {
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (row >= (long)p.B * p.T) return;
   const int b = (int)(row / p.T), t = (int)(row % p.T);
   const int len = clampi(p.logit_length[b], 0, p.T);
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
                                                     float *__restrict__ grad, int waves_per_block) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
-  const int w = threadIdx.x >> 6;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps everything derived from it in SGPRs
   const long row = (long)blockIdx.x * waves_per_block + w;
   if (row >= (long)p.B * p.T) return;
   const int b = (int)(row / p.T), t = (int)(row % p.T);
