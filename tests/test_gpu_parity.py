@@ -125,6 +125,22 @@ def test_random_reference_sizes(kind, B, T, V, seed):
 
 
 @pytest.mark.parametrize("kind", ["classic", "simplified"])
+@pytest.mark.parametrize("B,T,V,seed", [(8, 20, 8, 0), (5, 33, 7, 4)])
+def test_hessian_one_slab_per_wavefront_kernel(kind, B, T, V, seed, monkeypatch):
+    """Labels of at most 32 positions take the two-slabs-per-wavefront Hessian kernel; CTC_AMD_HESSIAN=slab forces the
+    general one (used for longer labels), which must give the same numbers."""
+    monkeypatch.setenv("CTC_AMD_HESSIAN", "slab")
+    _compare(kind, O.generate_ctc_loss_inputs(B, T, seed, V), ab=False)
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_hessian_label_longer_than_32(kind):
+    """U = 40 > 32: general Hessian kernel, compared with the oracle (T kept small: the oracle is O(T^2 L^2))."""
+    inp = O.generate_ctc_loss_inputs(2, 48, 40, 5, max_label_length=40)
+    _compare(kind, inp, ab=False)
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
 @pytest.mark.parametrize("T,V,U", [(40, 12, 17), (150, 33, 70), (200, 6, 130), (300, 9, 260)])
 def test_label_lengths_across_lane_tilings(kind, T, V, U):
     """U = 17 / 70 / 130 / 260 exercise 1, 2, 4 and 8 label positions per lane (NL) and repeated tokens."""

@@ -524,17 +524,27 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         float(*E)[LD::ES] = lds.E[DIR][j % 3];
         float smx = 0.f, sl2 = 0.f;  // lane d keeps the statistics of position d of the block
         if (nv == BLK) {
-          static_for<0, HQ>([&](auto Q) {
-            constexpr int q = decltype(Q)::value;
-            if (q < nq) {
-              const int d = pos1(q);
-              Emis<NL> e;
-              S.emit(xb[q], 0, e);
-              write_E(E[d], e);
-              smx = (lane == d) ? e.mx : smx;
-              sl2 = (lane == d) ? e.l2s : sl2;
+          auto emit_block = [&](auto NQ) __attribute__((always_inline)) {  // NQ frames of this helper in one batch
+            constexpr int nqc = decltype(NQ)::value;
+            if constexpr (nqc > 0) {
+              float4 xq[nqc][1];
+              Emis<NL> e[nqc];
+              static_for<0, nqc>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                xq[q][0] = make_float4(xb[q][0].x, xb[q][0].y, xb[q][0].z, xb[q][0].w);
+              });
+              S.template emit_n<nqc>(xq, e);
+              static_for<0, nqc>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                const int d = pos1(q);
+                write_E(E[d], e[q]);
+                smx = (lane == d) ? e[q].mx : smx;
+                sl2 = (lane == d) ? e[q].l2s : sl2;
+              });
             }
-          });
+          };
+          if (light) emit_block(std::integral_constant<int, LQ>{});
+          else emit_block(std::integral_constant<int, HQ>{});
         } else {
           for (int q = 0; q < nq; ++q) {
             const int d = pos1(q);

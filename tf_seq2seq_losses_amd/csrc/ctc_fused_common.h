@@ -4,6 +4,7 @@
 #include <type_traits>
 
 #include "ctc_common.h"
+#include "ctc_dpp_batch.h"
 
 namespace ctc {
 
@@ -232,6 +233,46 @@ struct Side {
     float mx, l2s;
     stats(xr, mx, l2s);
     gather(xr, parity, mx, l2s, e);
+  }
+
+  // Q frames at once: the two wave reductions of the statistics are batched (ctc_dpp_batch.h: no s_nop padding, one
+  // dependency chain of 6 levels instead of Q) and all LDS gathers are in flight before the first one is consumed.
+  // One LDS row copy serves all Q frames: LDS operations of a wavefront execute in program order.
+  template <int Q>
+  __device__ __forceinline__ void emit_n(const float4 (&xr)[Q][VPL], Emis<NL> (&e)[Q]) const {
+    float mx[Q], l2s[Q];
+    if constexpr (LOGITS) {
+      float m[Q];
+#pragma unroll
+      for (int f = 0; f < Q; ++f) {
+        m[f] = fmaxf(fmaxf(xr[f][0].x, xr[f][0].y), fmaxf(xr[f][0].z, xr[f][0].w));
+#pragma unroll
+        for (int q = 1; q < VPL; ++q) m[f] = fmaxf(m[f], fmaxf(fmaxf(xr[f][q].x, xr[f][q].y), fmaxf(xr[f][q].z, xr[f][q].w)));
+      }
+      dpp_max_n<Q>(m);
+      float sm[Q];
+#pragma unroll
+      for (int f = 0; f < Q; ++f) {
+        mx[f] = readlane_f(m[f], 63);
+        mx[f] = (mx[f] == -INFINITY) ? 0.f : mx[f];
+        sm[f] = 0.f;
+#pragma unroll
+        for (int q = 0; q < VPL; ++q)
+          sm[f] += fexp2((xr[f][q].x - mx[f]) * LOG2E) + fexp2((xr[f][q].y - mx[f]) * LOG2E) +
+                   fexp2((xr[f][q].z - mx[f]) * LOG2E) + fexp2((xr[f][q].w - mx[f]) * LOG2E);
+      }
+      dpp_sum_n<Q>(sm);
+#pragma unroll
+      for (int f = 0; f < Q; ++f) l2s[f] = flog2(readlane_f(sm[f], 63));
+    } else {
+#pragma unroll
+      for (int f = 0; f < Q; ++f) { mx[f] = 0.f; l2s[f] = 0.f; }
+    }
+    Raw w[Q];
+#pragma unroll
+    for (int f = 0; f < Q; ++f) gather_issue(xr[f], 0, w[f]);
+#pragma unroll
+    for (int f = 0; f < Q; ++f) gather_finish(w[f], mx[f], l2s[f], e[f]);
   }
 
   // one lattice step (identical recursions to Scan::step in ctc_kernels.hip)
