@@ -27,18 +27,23 @@ template <int KIND, int NL>
 __global__ __launch_bounds__(256) void hess_slab_kernel(Problem p, Layout L, const float *__restrict__ emis,
                                                          const float *__restrict__ alpha, const float *__restrict__ beta,
                                                          const double *__restrict__ logp, const float *__restrict__ g_lp,
-                                                         float *__restrict__ hess, int wpb) {
+                                                         const int *__restrict__ order, float *__restrict__ hess, int wpb,
+                                                         unsigned long long stride) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps everything derived from it in SGPRs
   const int T = p.T, V = p.V, UP = L.UP;
   const long ntask = (long)p.B * T * V;
-  const long task = (long)blockIdx.x * wpb + w;
+  // Task list: token-position major over the per-utterance order that lists the tokens present in the label first
+  // (hess_plan_kernel, below), walked with a stride permutation of the workgroups -- see hess_pair_kernel for why.
+  const long wg = (long)(((unsigned long long)blockIdx.x * stride) % gridDim.x);
+  const long task = wg * wpb + w;
   if (task >= ntask) return;
-  const int k1 = (int)(task % V);
-  const int t1 = (int)((task / V) % T);
-  const int b = (int)(task / ((long)V * T));
-  float *out = hess + task * ((long)T * V);
+  const int idx = (int)(task / ((long)p.B * T));
+  const int t1 = (int)(task % T);
+  const int b = (int)((task / T) % p.B);
+  const int k1 = order[(long)b * V + idx];
+  float *out = hess + (((long)b * T + t1) * V + k1) * ((long)T * V);
   const int len = clampi(p.logit_length[b], 0, T);
   int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
   const double lp = logp[b];
@@ -49,7 +54,11 @@ __global__ __launch_bounds__(256) void hess_slab_kernel(Problem p, Layout L, con
     if (t_to <= t_from) return;
     float *q = out + (long)t_from * V;
     const long n = (long)(t_to - t_from) * V;
-    for (long k = lane; k < n; k += 64) q[k] = 0.f;
+    if (((n | (q - hess)) & 3) == 0) {
+      for (long k = 4l * lane; k < n; k += 256) *reinterpret_cast<float4 *>(q + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      for (long k = lane; k < n; k += 64) q[k] = 0.f;
+    }
   };
   const bool valid = (t1 < len) && (lp != -INFINITY) && (ll <= p.U);
   if (!valid) {  // padded frame or infeasible sample: the whole slab is zero (base_loss.py:240-258)
@@ -114,11 +123,15 @@ __global__ __launch_bounds__(256) void hess_slab_kernel(Problem p, Layout L, con
     float y[NL], bl;
     float a[NL], b2[NL], tx, oh, ol;
   };
+  // wave-uniform values are fetched with VECTOR loads (scalar loads share lgkmcnt with the LDS traffic of emit_row and
+  // return out of order, so every LDS wait also waited for the prefetched tails of the next step); vz is an opaque zero
+  int vz;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
   auto load_e = [&](Pre &q, int t) {
     const float *er = erows + (long)t * L.ERS;
 #pragma unroll
     for (int j = 0; j < NL; ++j) q.y[j] = er[lane * NL + j];
-    q.bl = er[UP];
+    q.bl = er[UP + vz];
   };
   // beta row (workspace layout: slot i = state of l = i+1, the l = 0 state at the tail) as the forward sweep needs it
   auto load_fwd_row = [&](Pre &q, int trow) {
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(256) void hess_slab_kernel(Problem p, Layout L, con
       if constexpr (KIND == 0) { float2 v = *reinterpret_cast<const float2 *>(r + 2 * i); q.a[j] = v.x; q.b2[j] = v.y; }
       else { q.a[j] = r[i]; q.b2[j] = NEG; }
     }
-    q.tx = r[tailpos]; q.oh = r[tailpos + 2]; q.ol = r[tailpos + 3];
+    q.tx = r[tailpos + vz]; q.oh = r[tailpos + 2 + vz]; q.ol = r[tailpos + 3 + vz];
   };
   // alpha row shifted into the layout the backward sweep is aligned with: slot i = (state_c(l=i), open(l=i+1)), tail l=UP
   auto load_bwd_row = [&](Pre &q, int trow) {
@@ -140,7 +153,7 @@ __global__ __launch_bounds__(256) void hess_slab_kernel(Problem p, Layout L, con
       q.a[j] = (i == 0) ? r[tailpos] : r[PAIR * (i - 1)];
       q.b2[j] = (KIND == 0) ? r[2 * i + 1] : NEG;
     }
-    q.tx = r[PAIR * (UP - 1)]; q.oh = r[tailpos + 2]; q.ol = r[tailpos + 3];
+    q.tx = r[PAIR * (UP - 1) + vz]; q.oh = r[tailpos + 2 + vz]; q.ol = r[tailpos + 3 + vz];
   };
 
   // close one frame: scatter the joint posteriors and write the Hessian row of frame t2
@@ -306,8 +319,13 @@ __global__ __launch_bounds__(64) void hess_plan_kernel(Problem p, int *__restric
   "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"         \
   "s_nop 0"
 
+__host__ __device__ inline int pairs_per_frame(int V, int U) {
+  const int all = (V + 1) / 2, need = (U + 2) / 2;
+  return need < all ? need : all;
+}
+
 template <int KIND>
-__global__ __launch_bounds__(256) void hess_pair_kernel(Problem p, Layout L, const float *__restrict__ emis,
+__global__ __launch_bounds__(256, 6) void hess_pair_kernel(Problem p, Layout L, const float *__restrict__ emis,
                                                          const float *__restrict__ alpha, const float *__restrict__ beta,
                                                          const double *__restrict__ logp, const float *__restrict__ g_lp,
                                                          const int *__restrict__ order, const int *__restrict__ npres,
@@ -325,7 +343,9 @@ __global__ __launch_bounds__(256) void hess_pair_kernel(Problem p, Layout L, con
   const int hf = lane >> 5, hl = lane & 31;
   const bool first = hl == 0, last = hl == 31;
   const int T = p.T, V = p.V, UP = L.UP;
-  const int npair = (V + 1) / 2;
+  // wavefronts per (b, t1): one per pair of tokens that can be present (a label of U positions has at most U + 1
+  // distinct tokens, the blank included); the slabs of the other tokens are shared out among them (below)
+  const int npair = pairs_per_frame(V, p.U);
   const long ntask = (long)p.B * T * npair;
   const long task = (long)blockIdx.x * wpb + w;
   if (task >= ntask) return;
@@ -358,10 +378,18 @@ __global__ __launch_bounds__(256) void hess_pair_kernel(Problem p, Layout L, con
     if (have_b) fill_zero(out_b + (long)t_from * V, (long)(t_to - t_from) * V);
   };
   const bool valid = (t1 < len) && (lp != -INFINITY) && (ll <= p.U);
-  if (!valid) {  // padded frame or infeasible sample: both slabs are zero (base_loss.py:240-258)
-    zero_rows(0, T);
+  if (!valid) {  // padded frame or infeasible sample: all V slabs are zero (base_loss.py:240-258); this wavefront's share
+    for (int i = (int)(((long)pair * V) / npair); i < (int)(((long)(pair + 1) * V) / npair); ++i)
+      fill_zero(hess + (((long)b * T + t1) * V + i) * slab, slab);
     return;
   }
+  // Slabs of tokens absent from the label are zero apart from their diagonal row.  They are not given wavefronts of
+  // their own: the nh wavefronts of this (b, t1) that sweep share them and write them a little per sweep step (the
+  // sweeps are VALU-bound, the fills HBM-bound; run back to back they did not overlap: 5.4 ms = 3.5 + 1.9).
+  const int nh = (npres[b] + 1) / 2;   // pairs with at least one present token (the blank is always present)
+#ifndef CTC_HESS_DBG_NOSWEEP
+  if (pair >= nh) return;
+#endif
   const int32_t *lab = p.labels + (long)b * p.label_stride;
   auto tok = [&](int i) -> int { return (i >= 0 && i < ll) ? ((i < p.label_stride) ? lab[i] : p.blank) : -1 - (i < 0); };
   const int tk = tok(hl);
@@ -400,18 +428,74 @@ __global__ __launch_bounds__(256) void hess_pair_kernel(Problem p, Layout L, con
     }
   }
   zero_rows(len, T);  // columns beyond logit_length (base_loss.py:254-258)
-#ifdef CTC_HESS_DBG_NOFILL
-  if (2 * pair >= npres[b]) return;
-#endif
 #ifdef CTC_HESS_DBG_NOSWEEP
   if (true) {
-#else
-  if (2 * pair >= npres[b]) {  // both tokens absent from the label: no joint mass with any other frame
-#endif
     zero_rows(0, t1);
     zero_rows(t1 + 1, len);
     return;
   }
+#endif
+  // ---- this wavefront's share of the absent tokens' slabs: order positions [a_lo, a_hi) ----
+  const int na = V - 2 * nh;
+  const int a_lo = 2 * nh + (int)(((long)pair * na) / nh), a_hi = 2 * nh + (int)(((long)(pair + 1) * na) / nh);
+  const bool vec4 = (V & 3) == 0;
+  const int funit = vec4 ? 256 : 64;  // floats per fill instruction
+  const int *ord_b = order + (long)b * V;
+  {  // diagonal rows of the assigned slabs (g1 = 0 there, so only the log-softmax term of the logits-space Hessian is left)
+    const float *x = p.logits + ((long)b * T + t1) * V;
+    const float mx = erows[(long)t1 * L.ERS + UP + 1], l2s = erows[(long)t1 * L.ERS + UP + 2];
+    for (int i = a_lo; i < a_hi; ++i) {
+      const int kx = ord_b[i];
+      float *row = hess + (((long)b * T + t1) * V + kx) * slab + (long)t1 * V;
+      const float s1 = (p.wrt == 0) ? fexp2((x[kx] - mx) * LOG2E - l2s) : 0.f;
+      for (int k2 = lane; k2 < V; k2 += 64) {
+        float val = 0.f;
+        if (p.wrt == 0) val = (k2 == kx ? s1 : 0.f) - s1 * fexp2((x[k2] - mx) * LOG2E - l2s);
+        row[k2] = val;
+      }
+    }
+  }
+  // streaming zero fill of rows [0, t1) and (t1, T) of those slabs: wave-uniform cursor, one instruction per call
+  int f_idx = a_lo - 1, f_part = 1;
+  long f_left = 0;
+  float *f_ptr = hess;
+  bool f_done = a_lo >= a_hi;
+  auto f_advance = [&]() {
+    while (f_left == 0 && !f_done) {
+      if (f_part == 0) {
+        f_part = 1;
+        f_ptr += (long)V;  // skip the diagonal row
+        f_left = (long)(T - 1 - t1) * V;
+      } else {
+        ++f_idx;
+        if (f_idx >= a_hi) { f_done = true; break; }
+        const int kx = __builtin_amdgcn_readfirstlane(ord_b[f_idx]);
+        f_ptr = hess + (((long)b * T + t1) * V + kx) * slab;
+        f_part = 0;
+        f_left = (long)t1 * V;
+      }
+    }
+  };
+  f_advance();
+  auto fill_step = [&]() {
+    if (f_done) return;
+    const int n = f_left < funit ? (int)f_left : funit;
+    if (vec4) { if (4 * lane < n) *reinterpret_cast<float4 *>(f_ptr + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f); }
+    else if (lane < n) f_ptr[lane] = 0.f;
+    f_ptr += n;
+    f_left -= n;
+    if (f_left == 0) f_advance();
+  };
+  int f_per_row = 0;
+  {
+    const long per_slab = ((long)t1 * V + funit - 1) / funit + ((long)(T - 1 - t1) * V + funit - 1) / funit;
+    const long units = per_slab * (a_hi - a_lo);
+    const int rows = len - 1 > 0 ? len - 1 : 1;
+    f_per_row = (int)((units + rows - 1) / rows);
+  }
+#ifdef CTC_HESS_DBG_NOFILL
+  f_done = true;
+#endif
 
   // LDS per wavefront: two token rows (V + 4 each), then two staging buffers of SR output rows (burst writes, below)
   constexpr int SR = 8;
@@ -501,7 +585,6 @@ __global__ __launch_bounds__(256) void hess_pair_kernel(Problem p, Layout L, con
   };
   // Output rows are staged in LDS and written SR rows (SR*V*4 bytes, contiguous) at a time: with one 128-byte store per
   // row and ~10^4 slabs in flight the HBM write stream had no page locality (2.5 TB/s where a plain fill reaches 6.8).
-  const bool vec4 = (V & 3) == 0;
   auto flush = [&](int lo, int hi) {  // rows lo..hi of this half's slab, lo and hi in the same aligned group of SR rows
     __builtin_amdgcn_wave_barrier();
 #ifdef CTC_HESS_DBG_NOSTORE
@@ -562,6 +645,7 @@ __global__ __launch_bounds__(256) void hess_pair_kernel(Problem p, Layout L, con
       HST(0);
       load_e(nxt, tn);  // prefetch the next step while this one is processed
       load_fwd_row(nxt, tn + 1);
+      for (int f = 0; f < f_per_row; ++f) fill_step();  // after the loads: a wait for them does not wait for these stores
       const float sc = (float)((double)cur.oh + (off - lp)) + cur.ol;
       HST(1);
       float s1, s2, s0;
@@ -609,6 +693,7 @@ __global__ __launch_bounds__(256) void hess_pair_kernel(Problem p, Layout L, con
       const int tn = (t2 > 0) ? t2 - 1 : 0;
       load_e(nxt, tn);
       load_bwd_row(nxt, KIND == 0 ? tn + 1 : tn);
+      for (int f = 0; f < f_per_row; ++f) fill_step();
       const float sc = (float)((double)cur.oh + (off - lp)) + cur.ol;
       float s1, s2, s0;
       if constexpr (KIND == 0) {
@@ -624,6 +709,15 @@ __global__ __launch_bounds__(256) void hess_pair_kernel(Problem p, Layout L, con
       if ((t2 & (SR - 1)) == 0) { flush(t2, hi); hi = t2 - 1; }
     }
   }
+  while (!f_done) fill_step();  // whatever the sweeps did not get to (short utterances)
+}
+
+static unsigned long long wg_stride(long nblk) {  // odd stride near nblk / golden ratio, coprime to nblk
+  auto gcd = [](unsigned long long a, unsigned long long b) { while (b) { unsigned long long t = a % b; a = b; b = t; } return a; };
+  if (nblk < 8) return 1;
+  unsigned long long stride = (unsigned long long)((double)nblk * 0.6180339887) | 1ull;
+  while (gcd(stride, (unsigned long long)nblk) != 1) stride += 2;
+  return stride;
 }
 
 size_t hessian_extra_bytes(int kind, int B, int T, int V, int U) {
@@ -644,14 +738,10 @@ static hipError_t launch_pair(const Problem &p, const Layout &L, const float *em
   const size_t per_wave = (size_t)2 * (p.V + 4 + 8 * p.V) * 4;  // token rows + 8 staged output rows, per half
   while (wpb > 1 && wpb * per_wave > 64 * 1024) wpb >>= 1;
   const size_t shmem = wpb * per_wave;
-  const long ntask = (long)p.B * p.T * ((p.V + 1) / 2);
+  const long ntask = (long)p.B * p.T * pairs_per_frame(p.V, p.U);
   const long nblk = (ntask + wpb - 1) / wpb;
   if (nblk > 0x7fffffffL) return hipErrorInvalidValue;
-  // odd stride near nblk / golden ratio, coprime to nblk (see the kernel)
-  auto gcd = [](unsigned long long a, unsigned long long b) { while (b) { unsigned long long t = a % b; a = b; b = t; } return a; };
-  unsigned long long stride = (unsigned long long)((double)nblk * 0.6180339887) | 1ull;
-  while (stride > 1 && gcd(stride, (unsigned long long)nblk) != 1) stride += 2;
-  if (nblk < 8) stride = 1;
+  const unsigned long long stride = wg_stride(nblk);
   hipLaunchKernelGGL(hess_pair_kernel<KIND>, dim3((unsigned)nblk), dim3(64 * wpb), shmem, st, p, L, emis, alpha, beta, logp,
                      g_lp, order, npres, hess, wpb, stride, dbg);
   return hipGetLastError();
@@ -659,20 +749,24 @@ static hipError_t launch_pair(const Problem &p, const Layout &L, const float *em
 
 template <int KIND>
 static hipError_t launch_slab(const Problem &p, const Layout &L, const float *emis, const float *alpha, const float *beta,
-                              const double *logp, const float *g_lp, float *hess, hipStream_t st) {
+                              const double *logp, const float *g_lp, int *order, int *npres, float *hess, hipStream_t st) {
+  hipLaunchKernelGGL(hess_plan_kernel, dim3(p.B), dim3(64), (size_t)p.V, st, p, order, npres);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
   int wpb = 4;
   while (wpb > 1 && (size_t)wpb * (p.V + 4) * 4 > 64 * 1024) wpb >>= 1;
   const size_t shmem = (size_t)wpb * (p.V + 4) * 4;
   const long ntask = (long)p.B * p.T * p.V;
   const long nblk = (ntask + wpb - 1) / wpb;
   if (nblk > 0x7fffffffL) return hipErrorInvalidValue;
+  const unsigned long long stride = wg_stride(nblk);
   dim3 grid((unsigned)nblk), block(64 * wpb);
   switch (L.NL) {
-    case 1: hipLaunchKernelGGL((hess_slab_kernel<KIND, 1>), grid, block, shmem, st, p, L, emis, alpha, beta, logp, g_lp, hess, wpb); break;
-    case 2: hipLaunchKernelGGL((hess_slab_kernel<KIND, 2>), grid, block, shmem, st, p, L, emis, alpha, beta, logp, g_lp, hess, wpb); break;
-    case 4: hipLaunchKernelGGL((hess_slab_kernel<KIND, 4>), grid, block, shmem, st, p, L, emis, alpha, beta, logp, g_lp, hess, wpb); break;
-    case 8: hipLaunchKernelGGL((hess_slab_kernel<KIND, 8>), grid, block, shmem, st, p, L, emis, alpha, beta, logp, g_lp, hess, wpb); break;
-    case 16: hipLaunchKernelGGL((hess_slab_kernel<KIND, 16>), grid, block, shmem, st, p, L, emis, alpha, beta, logp, g_lp, hess, wpb); break;
+    case 1: hipLaunchKernelGGL((hess_slab_kernel<KIND, 1>), grid, block, shmem, st, p, L, emis, alpha, beta, logp, g_lp, order, hess, wpb, stride); break;
+    case 2: hipLaunchKernelGGL((hess_slab_kernel<KIND, 2>), grid, block, shmem, st, p, L, emis, alpha, beta, logp, g_lp, order, hess, wpb, stride); break;
+    case 4: hipLaunchKernelGGL((hess_slab_kernel<KIND, 4>), grid, block, shmem, st, p, L, emis, alpha, beta, logp, g_lp, order, hess, wpb, stride); break;
+    case 8: hipLaunchKernelGGL((hess_slab_kernel<KIND, 8>), grid, block, shmem, st, p, L, emis, alpha, beta, logp, g_lp, order, hess, wpb, stride); break;
+    case 16: hipLaunchKernelGGL((hess_slab_kernel<KIND, 16>), grid, block, shmem, st, p, L, emis, alpha, beta, logp, g_lp, order, hess, wpb, stride); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -684,19 +778,19 @@ hipError_t run_hessian(const Problem &p, const Layout &L, char *ws, const float 
   const float *alpha = reinterpret_cast<const float *>(ws + L.off_alpha);
   const float *beta = reinterpret_cast<const float *>(ws + L.off_beta);
   const double *logp = reinterpret_cast<const double *>(ws + L.off_logp);
+  auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+  char *ex = ws + L.off_extra + al((size_t)p.B * p.T * p.V * sizeof(float));
+  int *order = reinterpret_cast<int *>(ex);
+  int *npres = reinterpret_cast<int *>(ex + al((size_t)p.B * p.V * sizeof(int)));
   // short labels: two slabs per wavefront (CTC_AMD_HESSIAN=slab forces the one-slab kernel; the parity tests run both)
   const char *force = getenv("CTC_AMD_HESSIAN");
   if (p.U <= 32 && (size_t)2 * (p.V + 4 + 8 * p.V) * 4 <= 64 * 1024 && !(force && force[0] == 's')) {
-    auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
-    char *ex = ws + L.off_extra + al((size_t)p.B * p.T * p.V * sizeof(float));
-    int *order = reinterpret_cast<int *>(ex);
-    int *npres = reinterpret_cast<int *>(ex + al((size_t)p.B * p.V * sizeof(int)));
     unsigned long long *dbg = reinterpret_cast<unsigned long long *>(ws + L.off_dummy);  // diagnostic builds only
     return p.kind == 0 ? launch_pair<0>(p, L, emis, alpha, beta, logp, g_lp, order, npres, hess, dbg, st)
                        : launch_pair<1>(p, L, emis, alpha, beta, logp, g_lp, order, npres, hess, dbg, st);
   }
-  return p.kind == 0 ? launch_slab<0>(p, L, emis, alpha, beta, logp, g_lp, hess, st)
-                     : launch_slab<1>(p, L, emis, alpha, beta, logp, g_lp, hess, st);
+  return p.kind == 0 ? launch_slab<0>(p, L, emis, alpha, beta, logp, g_lp, order, npres, hess, st)
+                     : launch_slab<1>(p, L, emis, alpha, beta, logp, g_lp, order, npres, hess, st);
 }
 
 }  // namespace ctc
