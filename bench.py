@@ -78,8 +78,8 @@ def cpu_baseline(kind, host, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--kind", default="classic", choices=["classic", "simplified"])
     ap.add_argument("--B", type=int, default=256)
     ap.add_argument("--T", type=int, default=1000)
