@@ -19,4 +19,5 @@ NH=4; NW=4+2*NH
 st=ws[off_dummy:off_dummy+B*NW*32].view(torch.int64).cpu().numpy().reshape(B,NW,4)
 names=["main A","main B","recompute A","recompute B"]+[f"helper A{h}" for h in range(NH)]+[f"helper B{h}" for h in range(NH)]
 for i,nm in enumerate(names):
-    print(f"{nm}: work {st[:,i,0].mean():.0f} (phase1 {st[:,i,2].mean():.0f}, phase2 {st[:,i,0].mean()-st[:,i,2].mean():.0f})  barrier-wait {st[:,i,1].mean():.0f} cycles")
+    w, wt, w1, wt1 = (st[:, i, k].mean() for k in range(4))
+    print(f"{nm:12s}: phase1 work {w1:7.0f} wait {wt1:7.0f} | phase2 work {w - w1:7.0f} wait {wt - wt1:7.0f} | total {w + wt:7.0f} cycles")

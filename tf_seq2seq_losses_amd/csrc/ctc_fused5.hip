@@ -42,13 +42,13 @@ __device__ __forceinline__ void block_barrier() {
 #ifdef CTC_FUSED_STAMPS
 // Diagnostic build only: per-wavefront cycles spent working vs. waiting at the block barrier (written to the sink area).
 struct Stamps {
-  unsigned long long work = 0, wait = 0, t0 = 0, work1 = 0;
+  unsigned long long work = 0, wait = 0, t0 = 0, work1 = 0, wait1 = 0;
   __device__ __forceinline__ void begin() { t0 = __builtin_amdgcn_s_memtime(); }
   __device__ __forceinline__ void mid() { unsigned long long t = __builtin_amdgcn_s_memtime(); work += t - t0; t0 = t; }
   __device__ __forceinline__ void end() { unsigned long long t = __builtin_amdgcn_s_memtime(); wait += t - t0; t0 = t; }
-  __device__ __forceinline__ void phase1_done() { work1 = work; }
+  __device__ __forceinline__ void phase1_done() { work1 = work; wait1 = wait; }
   __device__ __forceinline__ void dump(unsigned long long *dst, int lane) {
-    if (lane == 0) { dst[0] = work; dst[1] = wait; dst[2] = work1; dst[3] = 0; }
+    if (lane == 0) { dst[0] = work; dst[1] = wait; dst[2] = work1; dst[3] = wait1; }
   }
 };
 #define STAMP(x) x
