@@ -40,7 +40,6 @@ __device__ __forceinline__ void block_barrier() {
 }
 
 #ifdef CTC_FUSED_STAMPS
-// Diagnostic build only: per-wavefront cycles spent working vs. waiting at the block barrier (written to the sink area).
 struct Stamps {
   unsigned long long work = 0, wait = 0, t0 = 0, work1 = 0, wait1 = 0;
   __device__ __forceinline__ void begin() { t0 = __builtin_amdgcn_s_memtime(); }
@@ -51,10 +50,16 @@ struct Stamps {
     if (lane == 0) { dst[0] = work; dst[1] = wait; dst[2] = work1; dst[3] = wait1; }
   }
 };
-#define STAMP(x) x
 #else
-#define STAMP(x)
+struct Stamps {  // normal builds: nothing
+  __device__ __forceinline__ void begin() {}
+  __device__ __forceinline__ void mid() {}
+  __device__ __forceinline__ void end() {}
+  __device__ __forceinline__ void phase1_done() {}
+  __device__ __forceinline__ void dump(unsigned long long *, int) {}
+};
 #endif
+#define STAMP(x) x
 
 template <int KIND, int NL, int NH, int BLK>
 struct Lds {
@@ -66,6 +71,7 @@ struct Lds {
   float E[2][3][BLK][ES];   // [side][block % 3]
   float R[2][3][BLK][RS];   // [side][block % 3]
   float xcopy[2 * NH][V + 4];
+  float xcopy_r[2][V + 4];  // row copies of the recompute waves (E stage of phase 1)
   float bins[2 * NH][V + 4];
   float dump[NW][64];
   int feasible;
@@ -200,6 +206,108 @@ __device__ __forceinline__ void init_labels(Side<KIND, NL, 1, DIR, true> &S, con
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) S.mb[e] = (lane * 4 + e == p.blank) ? 1.f : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// E stage of phase 1 (logits rows -> log-softmax statistics -> emission rows in LDS), shared by the helpers and by the
+// recompute wavefronts, which have no lattice work before the meeting point.  Positions of a 12-frame block of side
+// SIDE are dealt out by SIMD: the two helpers that share a SIMD with a main chain take X each, the two on the recompute
+// SIMDs Y each, the side's recompute wavefront the remaining R = 12 - 2X - 2Y (SIMD 0/1 carry the chains' 2.5 k VALU
+// cycles per block, SIMD 2/3 nothing else in this phase).  The worker also records the statistics of its frames for the
+// other side's pass over them in phase 2.  One barrier per block, like every other role.
+// ------------------------------------------------------------------------------------------------
+#ifndef CTC_F5_X
+#define CTC_F5_X 1
+#endif
+#ifndef CTC_F5_Y
+#define CTC_F5_Y 3
+#endif
+template <int BLK>
+struct P1Split {
+  static constexpr int X = CTC_F5_X, Y = CTC_F5_Y, R = BLK - 2 * X - 2 * Y;
+  static_assert(X >= 0 && Y >= 0 && R >= 0 && X <= 6 && Y <= 6 && R <= 6, "phase-1 split: at most 6 frames per worker");
+  // worker: 0, 1 = helpers on the chain SIMDs, 2, 3 = helpers on the recompute SIMDs, 4 = recompute wavefront
+  static constexpr int first(int worker) { return worker == 0 ? 0 : worker == 1 ? X : worker == 2 ? 2 * X : worker == 3 ? 2 * X + Y : 2 * X + 2 * Y; }
+  static constexpr int count(int worker) { return worker < 2 ? X : worker < 4 ? Y : R; }
+};
+
+template <int KIND, int NL, int NH, int BLK, int SIDE, int P0, int NQ, class S_t>
+__device__ __forceinline__ void estage1(const S_t &S, Lds<KIND, NL, NH, BLK> &lds, const Geo<BLK> &geo,
+                                        float2 *__restrict__ stats, float *dump, int lane, Stamps &st) {
+  using LD = Lds<KIND, NL, NH, BLK>;
+  const int len = geo.len;
+  const int nb = geo.nblocks(1, SIDE);
+  auto write_E = [&](float *row, const Emis<NL> &e) __attribute__((always_inline)) {
+    float *q = row + lane * NL;
+    if constexpr (NL == 1) q[0] = e.y[0];
+    else *reinterpret_cast<float2 *>(q) = make_float2(e.y[0], e.y[1]);
+    float *tq = (lane == 0) ? row + LD::UP : dump + (lane & 15) * 4;  // lanes >= 16 overlap in the sink: harmless
+    *reinterpret_cast<float4 *>(tq) = make_float4(e.bl, e.mx, e.l2s, 0.f);
+  };
+  auto fr = [&](int j, int d) -> int {  // frame at position d of this side's block j, clamped so prefetches stay legal
+    int jj = j < nb ? j : nb - 1;
+    jj = jj < 0 ? 0 : jj;
+    const int g = geo.absblock(1, SIDE, jj);
+    const int nv = geo.nvof(g);
+    int dd = d < nv ? d : nv - 1;
+    int t = geo.frame(SIDE, g, dd < 0 ? 0 : dd);
+    t = t < len ? t : len - 1;
+    return t < 0 ? 0 : t;
+  };
+  constexpr int NQA = NQ > 0 ? NQ : 1;
+  float4 xb[NQA][1];
+  static_for<0, NQA>([&](auto Q) {
+    constexpr int q = decltype(Q)::value;
+    xb[q][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (NQ > 0 && nb > 0) S.load_x(xb[q], fr(0, P0 + q));
+  });
+  for (int it = 0; it <= geo.NB; ++it) {
+    const int j = it;
+    if (NQ > 0 && j < nb) {
+      const int g = geo.absblock(1, SIDE, j);
+      const int nv = geo.nvof(g);
+      float(*E)[LD::ES] = lds.E[SIDE][j % 3];
+      float smx = 0.f, sl2 = 0.f;  // lane d keeps the statistics of position d of the block
+      if (nv == BLK) {
+        if constexpr (NQ > 0) {
+          float4 xq[NQA][1];
+          Emis<NL> e[NQA];
+          static_for<0, NQA>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            xq[q][0] = make_float4(xb[q][0].x, xb[q][0].y, xb[q][0].z, xb[q][0].w);
+          });
+          S.template emit_n<NQA>(xq, e);  // NQ frames in one batch
+          static_for<0, NQA>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            write_E(E[P0 + q], e[q]);
+            smx = (lane == P0 + q) ? e[q].mx : smx;
+            sl2 = (lane == P0 + q) ? e[q].l2s : sl2;
+          });
+        }
+      } else {
+        for (int q = 0; q < NQ; ++q) {
+          const int d = P0 + q;
+          if (d < nv) {
+            float4 xr[1];
+            S.load_x(xr, geo.frame(SIDE, g, d));
+            Emis<NL> e;
+            S.emit(xr, 0, e);
+            write_E(E[d], e);
+            smx = (lane == d) ? e.mx : smx;
+            sl2 = (lane == d) ? e.l2s : sl2;
+          }
+        }
+      }
+      static_for<0, NQA>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        S.load_x(xb[q], fr(j + 1, P0 + q));
+      });
+      if (lane >= P0 && lane < P0 + NQ && lane < nv) stats[geo.frame(SIDE, g, lane)] = make_float2(smx, sl2);
+    }
+    st.mid();
+    block_barrier();
+    st.end();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -347,8 +455,8 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
 // ------------------------------------------------------------------------------------------------
 template <int KIND, int NL, int NH, int BLK, int SIDE>
 __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L, const float *__restrict__ alpha_ws,
-                                              const float *__restrict__ beta_ws, Lds<KIND, NL, NH, BLK> &lds,
-                                              const Geo<BLK> &geo, void *stamp_ws) {
+                                              const float *__restrict__ beta_ws, float2 *__restrict__ stats_ws,
+                                              Lds<KIND, NL, NH, BLK> &lds, const Geo<BLK> &geo, void *stamp_ws) {
   constexpr int RDIR = 1 - SIDE;  // direction of the recursion this wave runs
   using S_t = Side<KIND, NL, 1, RDIR, true>;
   using LD = Lds<KIND, NL, NH, BLK>;
@@ -368,10 +476,13 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
   float *dump = lds.dump[2 + SIDE];
   STAMP(Stamps st; st.begin());
 
-  for (int it = 0; it <= geo.NB; ++it) {  // phase 1: nothing to recompute
-    STAMP(st.mid());
-    block_barrier();
-    STAMP(st.end());
+  {  // phase 1: nothing to recompute yet -- this wavefront works the E stage of its side (estage1)
+    using SP = P1Split<BLK>;
+    S.xbase = p.logits + (long)b * T * 256;
+    S.xs = lds.xcopy_r[SIDE];
+    if (lane == 0) S.xs[256] = -6.0e29f;  // pad slot of the gather copy: "log 0" for label positions beyond label_length
+    float2 *stats = stats_ws + (long)b * T;
+    estage1<KIND, NL, NH, BLK, SIDE, SP::first(4), SP::count(4)>(S, lds, geo, stats, dump, lane, st);
   }
   STAMP(st.phase1_done());
   __syncthreads();
@@ -495,79 +606,15 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
     return t < 0 ? 0 : t;
   };
 
-  // ================= phase 1: E stage with statistics (recorded for the other side's pass over the same frames) =========
-  // Uneven split: helpers 0 .. NH/2-1 sit on the SIMDs of the two main chains and take LQ positions of each block,
-  // helpers NH/2 .. NH-1 sit on the SIMDs of the recompute chains -- idle in this phase -- and take HQ.
+  // ================= phase 1: E stage with statistics (estage1 above) =================
   {
-    static_assert(BLK == 12 && NH == 4, "phase-1 position map is written for BLK = 12, NH = 4");
-#ifndef CTC_F5_LQ
-#define CTC_F5_LQ 2
-#endif
-    constexpr int LQ = CTC_F5_LQ, HQ = BLK / 2 - LQ;
-    const bool light = h < NH / 2;
-    const int nq = light ? LQ : HQ;
-    // positions of parity r = h & 1 are r, r+2, .., r+10: the light helper takes the first LQ of them, the heavy one the rest
-    auto pos1 = [&](int q) -> int { return (h & 1) + 2 * (light ? q : LQ + q); };
-    auto owner1 = [&](int d) -> int { return ((d >> 1) < LQ) ? (d & 1) : 2 + (d & 1); };
-    const int nb = geo.nblocks(1, DIR);
-    float4 xb[HQ][1];
-    static_for<0, HQ>([&](auto Q) {
-      constexpr int q = decltype(Q)::value;
-      xb[q][0] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (nb > 0 && q < nq) S.load_x(xb[q], fr(1, 0, pos1(q)));
-    });
-    for (int it = 0; it <= geo.NB; ++it) {
-      const int j = it;
-      if (j < nb) {
-        const int g = geo.absblock(1, DIR, j);
-        const int nv = geo.nvof(g);
-        float(*E)[LD::ES] = lds.E[DIR][j % 3];
-        float smx = 0.f, sl2 = 0.f;  // lane d keeps the statistics of position d of the block
-        if (nv == BLK) {
-          auto emit_block = [&](auto NQ) __attribute__((always_inline)) {  // NQ frames of this helper in one batch
-            constexpr int nqc = decltype(NQ)::value;
-            if constexpr (nqc > 0) {
-              float4 xq[nqc][1];
-              Emis<NL> e[nqc];
-              static_for<0, nqc>([&](auto Q) {
-                constexpr int q = decltype(Q)::value;
-                xq[q][0] = make_float4(xb[q][0].x, xb[q][0].y, xb[q][0].z, xb[q][0].w);
-              });
-              S.template emit_n<nqc>(xq, e);
-              static_for<0, nqc>([&](auto Q) {
-                constexpr int q = decltype(Q)::value;
-                const int d = pos1(q);
-                write_E(E[d], e[q]);
-                smx = (lane == d) ? e[q].mx : smx;
-                sl2 = (lane == d) ? e[q].l2s : sl2;
-              });
-            }
-          };
-          if (light) emit_block(std::integral_constant<int, LQ>{});
-          else emit_block(std::integral_constant<int, HQ>{});
-        } else {
-          for (int q = 0; q < nq; ++q) {
-            const int d = pos1(q);
-            if (d < nv) {
-              float4 xr[1];
-              S.load_x(xr, geo.frame(DIR, g, d));
-              Emis<NL> e;
-              S.emit(xr, 0, e);
-              write_E(E[d], e);
-              smx = (lane == d) ? e.mx : smx;
-              sl2 = (lane == d) ? e.l2s : sl2;
-            }
-          }
-        }
-        static_for<0, HQ>([&](auto Q) {
-          constexpr int q = decltype(Q)::value;
-          if (q < nq) S.load_x(xb[q], fr(1, j + 1, pos1(q)));
-        });
-        if (lane < nv && owner1(lane) == h) stats[geo.frame(DIR, g, lane)] = make_float2(smx, sl2);
-      }
-      STAMP(st.mid());
-      block_barrier();
-      STAMP(st.end());
+    using SP = P1Split<BLK>;
+    static_assert(NH == 4, "phase-1 split is written for 4 helpers per side");
+    switch (h) {
+      case 0: estage1<KIND, NL, NH, BLK, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, dump, lane, st); break;
+      case 1: estage1<KIND, NL, NH, BLK, DIR, SP::first(1), SP::count(1)>(S, lds, geo, stats, dump, lane, st); break;
+      case 2: estage1<KIND, NL, NH, BLK, DIR, SP::first(2), SP::count(2)>(S, lds, geo, stats, dump, lane, st); break;
+      default: estage1<KIND, NL, NH, BLK, DIR, SP::first(3), SP::count(3)>(S, lds, geo, stats, dump, lane, st); break;
     }
   }
 
@@ -714,10 +761,10 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused5_kernel(Problem p, La
     run_main<KIND, NL, NH, BLK, 1>(p, L, alpha_ws, beta_ws, logp_ws, loss, lds, geo, stamp_ws);
   } else if (w == 2) {
     __builtin_amdgcn_s_setprio(2);
-    run_recompute<KIND, NL, NH, BLK, 0>(p, L, alpha_ws, beta_ws, lds, geo, stamp_ws);
+    run_recompute<KIND, NL, NH, BLK, 0>(p, L, alpha_ws, beta_ws, stats_ws, lds, geo, stamp_ws);
   } else if (w == 3) {
     __builtin_amdgcn_s_setprio(2);
-    run_recompute<KIND, NL, NH, BLK, 1>(p, L, alpha_ws, beta_ws, lds, geo, stamp_ws);
+    run_recompute<KIND, NL, NH, BLK, 1>(p, L, alpha_ws, beta_ws, stats_ws, lds, geo, stamp_ws);
   } else if (w < 4 + NH) {
     run_helper<KIND, NL, NH, BLK, 0>(p, L, stats_ws, d_loss, grad, lds, geo, w - 4, stamp_ws);
   } else {
