@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--hessian", action="store_true", help="time the dense Hessian at B=32 T=200 U=32 V=64 (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="element type of logits and gradient (producer format)")
+    ap.add_argument("--time-major", action="store_true", help="logits stored [T,B,V] (producer format), passed as a strided view")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse ranks that share one GPU)")
     args = ap.parse_args()
@@ -137,14 +139,31 @@ def main():
         loss = torch.empty(B, dtype=torch.float32, device=device)
         grad = torch.empty((B, T, V), dtype=torch.float32, device=device)
         lib = _lib.load()
-        args_c = prep.common(kind, _lib.WRT_LOGITS) + (loss.data_ptr(), grad.data_ptr(), None, ws.data_ptr(), ws.numel())
+        native = args.dtype != "f32" or args.time_major
+        if native:  # producer formats through ctc_amd_loss_grad_ex: no conversion pass anywhere
+            xf = dev["logits"].to(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+            if args.time_major:
+                xf = xf.transpose(0, 1).contiguous().transpose(0, 1)
+            grad = torch.empty_strided(xf.shape, xf.stride(), dtype=xf.dtype, device=device)
+            dt = _lib.BF16 if args.dtype == "bf16" else _lib.F32
+            ex_args = (kind, _lib.WRT_LOGITS, xf.data_ptr(), dt, xf.stride(0), xf.stride(1), prep.labels.data_ptr(), prep.stride,
+                       prep.label_length.data_ptr(), prep.logit_length.data_ptr(), 0, B, T, V, U, loss.data_ptr(),
+                       grad.data_ptr(), dt, xf.stride(0), xf.stride(1), None, ws.data_ptr(), ws.numel())
 
-        def step():
-            rc = lib.ctc_amd_loss_grad(*args_c, torch.cuda.current_stream().cuda_stream)
-            if rc:
-                _lib.check(rc, "ctc_amd_loss_grad")
-            return loss
-        alg_bytes = B * 2 * T * V * 4
+            def step():
+                rc = lib.ctc_amd_loss_grad_ex(*ex_args, torch.cuda.current_stream().cuda_stream)
+                if rc:
+                    _lib.check(rc, "ctc_amd_loss_grad_ex")
+                return loss
+        else:
+            args_c = prep.common(kind, _lib.WRT_LOGITS) + (loss.data_ptr(), grad.data_ptr(), None, ws.data_ptr(), ws.numel())
+
+            def step():
+                rc = lib.ctc_amd_loss_grad(*args_c, torch.cuda.current_stream().cuda_stream)
+                if rc:
+                    _lib.check(rc, "ctc_amd_loss_grad")
+                return loss
+        alg_bytes = B * 2 * T * V * (2 if args.dtype == "bf16" else 4)
 
     # The reduced scalar is read one step later (a training loop logs it), so the all-reduce of step i is issued
     # asynchronously and runs on RCCL's stream beside the kernel of step i+1; every collective still completes inside the
@@ -216,6 +235,7 @@ def main():
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "r01_fused5_pmc_traffic.json")
             if pipeline == "fused5" and args.kind == "classic" and (B, T, U, V) == (256, 1000, 128, 256) and not args.ragged \
+                    and args.dtype == "f32" and not args.time_major \
                     and os.path.exists(tfile):
                 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file's note)
                 traffic = json.load(open(tfile)).get("_total_bytes_per_call")
@@ -224,9 +244,9 @@ def main():
             else "utterances/sec (dense Hessian) at B=32 T=200 U=32 V=64",
             "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.dtype == "f32" else "f32 arithmetic, bf16 logits/gradient in HBM", "data": "synthetic",
             "config": {"workload": f"{args.kind}_ctc_loss {'hessian' if args.hessian else 'loss+grad'} B={B} T={T} U={U} V={V} fp32 per GPU"
-                                   + (" ragged" if args.ragged else " full-length"),
+                                   + (" ragged" if args.ragged else " full-length") + (" time-major [T,B,V]" if args.time_major else ""),
                        "global_batch": B * world, "parallelism": f"batch-sharded x{world}, all-reduce of sum(loss)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

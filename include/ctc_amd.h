@@ -58,6 +58,10 @@ extern "C" {
 #define CTC_AMD_WS_HESSIAN 2
 #define CTC_AMD_WS_HVP 3
 
+/* element types of the producer formats (ctc_amd_loss_grad_ex) */
+#define CTC_AMD_F32 0
+#define CTC_AMD_BF16 1
+
 /* ABI version of the loaded library (== CTC_AMD_ABI_VERSION of the header it was built from). */
 int ctc_amd_abi_version(void);
 
@@ -114,6 +118,23 @@ int ctc_amd_hessian(int kind, int wrt,
                     int B, int T, int V, int U,
                     float *loss, float *grad, float *hess,
                     void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * ctc_amd_loss_grad for the formats a producer kernel hands over: logits (and the gradient written back) as float32 or
+ * bfloat16, with arbitrary element strides of the batch and time axes -- time-major [T,B,V] activations are
+ * logits_stride_b = V, logits_stride_t = B*V; the token axis is contiguous.  Arithmetic is float32 either way.
+ * Replaces: the `logit_to_logproba` entry of ctc_loss (base_loss.py:59, tools.py:27-40), which the reference can only
+ * feed with a contiguous float32 [B,T,V] tensor (a transposed or bfloat16 producer pays one more 262 MB pass there).
+ * SURVEY.md section 8(f) rank 3.  Workspace: CTC_AMD_WS_LOSS_GRAD.  Strides are in elements and must be >= V.
+ */
+int ctc_amd_loss_grad_ex(int kind, int wrt,
+                         const void *logits, int logits_dtype, int64_t logits_stride_b, int64_t logits_stride_t,
+                         const int32_t *labels, int label_stride,
+                         const int32_t *label_length, const int32_t *logit_length, int blank_index,
+                         int B, int T, int V, int U,
+                         float *loss, void *grad, int grad_dtype, int64_t grad_stride_b, int64_t grad_stride_t,
+                         const float *d_loss,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Hessian-vector product  out[b,t,k] = sum_{t2,k2} H[b,t,k,t2,k2] * vec[b,t2,k2]  without materialising H

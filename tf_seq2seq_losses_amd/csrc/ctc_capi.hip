@@ -15,8 +15,13 @@ hipError_t run_fused_simplified(const Problem &p, const Layout &L, char *ws, flo
 hipError_t run_fused5_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 hipError_t run_fused5_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 // shapes the checkpoint + recompute kernel (ctc_fused5.hip) is instantiated for: logits input, V = 256, U <= 128
+inline bool plain_format(const Problem &p) {  // contiguous float32 [B,T,V] logits and gradient
+  return p.xdtype == 0 && p.gdtype == 0 && p.xst == p.V && p.gst == p.V && p.xsb == (long)p.T * p.V && p.gsb == (long)p.T * p.V;
+}
 inline bool fused5_eligible(const Problem &p, const Layout &L) {
-  return p.wrt == 0 && p.V == 256 && L.NL <= 2 && p.B > 0 && p.T > 0;
+  // producer formats: both tensors float32 or both bfloat16, strides keeping the 16-byte (8-byte) row accesses aligned
+  return p.wrt == 0 && p.V == 256 && L.NL <= 2 && p.B > 0 && p.T > 0 && p.xdtype == p.gdtype &&
+         ((p.xsb | p.xst | p.gsb | p.gst) & 3) == 0;
 }
 inline hipError_t run_fused5(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
   return p.kind == 0 ? run_fused5_classic(p, L, ws, loss, d_loss, grad, st) : run_fused5_simplified(p, L, ws, loss, d_loss, grad, st);
@@ -25,14 +30,14 @@ hipError_t run_fused4_classic(const Problem &p, const Layout &L, char *ws, float
 hipError_t run_fused4_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 // shapes the chain + helper kernel (ctc_fused4.hip) is instantiated for: logits input, V = 256, U <= 128 (LDS budget)
 inline bool fused4_eligible(const Problem &p, const Layout &L) {
-  return p.wrt == 0 && p.V == 256 && L.NL <= 2 && p.B > 0 && p.T > 0;
+  return p.wrt == 0 && p.V == 256 && L.NL <= 2 && p.B > 0 && p.T > 0 && plain_format(p);
 }
 inline hipError_t run_fused4(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
   return p.kind == 0 ? run_fused4_classic(p, L, ws, loss, d_loss, grad, st) : run_fused4_simplified(p, L, ws, loss, d_loss, grad, st);
 }
 // shapes the two-wavefront fused kernel (ctc_fused.hip) is instantiated for: logits input, V in {256, 512, 1024}, U <= 256
 inline bool fused_eligible(const Problem &p, const Layout &L) {
-  return p.wrt == 0 && (p.V == 256 || p.V == 512 || p.V == 1024) && L.NL <= 4 && p.B > 0 && p.T > 0;
+  return p.wrt == 0 && (p.V == 256 || p.V == 512 || p.V == 1024) && L.NL <= 4 && p.B > 0 && p.T > 0 && plain_format(p);
 }
 inline hipError_t run_fused(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
   return p.kind == 0 ? run_fused_classic(p, L, ws, loss, d_loss, grad, st) : run_fused_simplified(p, L, ws, loss, d_loss, grad, st);
@@ -77,6 +82,7 @@ ctc::Problem make_problem(int kind, int wrt, const float *logits, const int32_t 
   ctc::Problem p;
   p.logits = logits; p.labels = labels; p.label_length = label_length; p.logit_length = logit_length;
   p.label_stride = label_stride; p.blank = blank; p.B = B; p.T = T; p.V = V; p.U = U; p.kind = kind; p.wrt = wrt;
+  p.xsb = (long)T * V; p.xst = V; p.gsb = (long)T * V; p.gst = V; p.xdtype = 0; p.gdtype = 0;  // contiguous float32
   return p;
 }
 
@@ -125,6 +131,32 @@ int ctc_amd_workspace_bytes(int what, int kind, int B, int T, int V, int U, size
   return CTC_AMD_OK;
 }
 
+static int loss_grad_impl(ctc::Problem p, float *loss, void *grad, const float *d_loss, void *workspace,
+                          size_t workspace_bytes, void *stream) {
+  if (!loss) return fail(CTC_AMD_EINVAL, "null loss pointer");
+  if (grad && p.V > MAX_V_GRAD) return fail(CTC_AMD_EINVAL, "V=%d exceeds the supported maximum %d for the gradient", p.V, MAX_V_GRAD);
+  ctc::Layout L = ctc::make_layout(p.kind, p.B, p.T, p.U, 0);
+  if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float *gradf = static_cast<float *>(grad);  // element-typed inside the kernels (Problem::gdtype)
+  const char *pl = select_pipeline(p, L, grad != nullptr);
+  if (pl[0] == 'f') {
+    char *wsb = static_cast<char *>(workspace);
+    hipError_t ef = (pl[5] == '5') ? ctc::run_fused5(p, L, wsb, loss, d_loss, gradf, st)
+                  : (pl[5] == '4') ? ctc::run_fused4(p, L, wsb, loss, d_loss, gradf, st)
+                                   : ctc::run_fused(p, L, wsb, loss, d_loss, gradf, st);
+    if (ef != hipSuccess) return hip_fail(ef, pl);
+    return CTC_AMD_OK;
+  }
+  hipError_t e = ctc::run_emit_scan(p, L, static_cast<char *>(workspace), loss, grad ? 2 : 1, st);
+  if (e != hipSuccess) return hip_fail(e, "emit/scan launch");
+  if (grad) {
+    e = ctc::run_grad(p, L, static_cast<char *>(workspace), d_loss, gradf, st);
+    if (e != hipSuccess) return hip_fail(e, "grad launch");
+  }
+  return CTC_AMD_OK;
+}
+
 int ctc_amd_loss_grad(int kind, int wrt, const float *logits, const int32_t *labels, int label_stride,
                       const int32_t *label_length, const int32_t *logit_length, int blank_index, int B, int T, int V,
                       int U, float *loss, float *grad, const float *d_loss, void *workspace, size_t workspace_bytes,
@@ -132,28 +164,30 @@ int ctc_amd_loss_grad(int kind, int wrt, const float *logits, const int32_t *lab
   int rc = check_common(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
   if (rc) return rc;
   if (B == 0) return CTC_AMD_OK;
-  if (!loss) return fail(CTC_AMD_EINVAL, "null loss pointer");
-  if (grad && V > MAX_V_GRAD) return fail(CTC_AMD_EINVAL, "V=%d exceeds the supported maximum %d for the gradient", V, MAX_V_GRAD);
-  ctc::Layout L = ctc::make_layout(kind, B, T, U, 0);
-  if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
   ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const char *pl = select_pipeline(p, L, grad != nullptr);
-  if (pl[0] == 'f') {
-    char *wsb = static_cast<char *>(workspace);
-    hipError_t ef = (pl[5] == '5') ? ctc::run_fused5(p, L, wsb, loss, d_loss, grad, st)
-                  : (pl[5] == '4') ? ctc::run_fused4(p, L, wsb, loss, d_loss, grad, st)
-                                   : ctc::run_fused(p, L, wsb, loss, d_loss, grad, st);
-    if (ef != hipSuccess) return hip_fail(ef, pl);
-    return CTC_AMD_OK;
-  }
-  hipError_t e = ctc::run_emit_scan(p, L, static_cast<char *>(workspace), loss, grad ? 2 : 1, st);
-  if (e != hipSuccess) return hip_fail(e, "emit/scan launch");
-  if (grad) {
-    e = ctc::run_grad(p, L, static_cast<char *>(workspace), d_loss, grad, st);
-    if (e != hipSuccess) return hip_fail(e, "grad launch");
-  }
-  return CTC_AMD_OK;
+  return loss_grad_impl(p, loss, grad, d_loss, workspace, workspace_bytes, stream);
+}
+
+int ctc_amd_loss_grad_ex(int kind, int wrt, const void *logits, int logits_dtype, int64_t logits_stride_b,
+                         int64_t logits_stride_t, const int32_t *labels, int label_stride, const int32_t *label_length,
+                         const int32_t *logit_length, int blank_index, int B, int T, int V, int U, float *loss, void *grad,
+                         int grad_dtype, int64_t grad_stride_b, int64_t grad_stride_t, const float *d_loss, void *workspace,
+                         size_t workspace_bytes, void *stream) {
+  int rc = check_common(kind, wrt, static_cast<const float *>(logits), labels, label_stride, label_length, logit_length,
+                        blank_index, B, T, V, U);
+  if (rc) return rc;
+  if ((logits_dtype != CTC_AMD_F32 && logits_dtype != CTC_AMD_BF16) || (grad_dtype != CTC_AMD_F32 && grad_dtype != CTC_AMD_BF16))
+    return fail(CTC_AMD_EINVAL, "dtype must be CTC_AMD_F32 or CTC_AMD_BF16 (logits %d, grad %d)", logits_dtype, grad_dtype);
+  if (B == 0) return CTC_AMD_OK;
+  // rows must not overlap: |stride_t| >= V, and the batch stride must step over whole rows in either nesting order
+  if (logits_stride_t < V || logits_stride_b < V || (grad && (grad_stride_t < V || grad_stride_b < V)))
+    return fail(CTC_AMD_EINVAL, "strides smaller than a row of V=%d elements (logits %lld/%lld, grad %lld/%lld)", V,
+                (long long)logits_stride_b, (long long)logits_stride_t, (long long)grad_stride_b, (long long)grad_stride_t);
+  ctc::Problem p = make_problem(kind, wrt, static_cast<const float *>(logits), labels, label_stride, label_length, logit_length,
+                                blank_index, B, T, V, U);
+  p.xsb = logits_stride_b; p.xst = logits_stride_t; p.xdtype = logits_dtype;
+  p.gsb = grad_stride_b; p.gst = grad_stride_t; p.gdtype = grad_dtype;
+  return loss_grad_impl(p, loss, grad, d_loss, workspace, workspace_bytes, stream);
 }
 
 int ctc_amd_alpha_beta(int kind, int wrt, const float *logits, const int32_t *labels, int label_stride,

@@ -57,7 +57,20 @@ struct Problem {
   const int32_t *label_length;
   const int32_t *logit_length;
   int label_stride, blank, B, T, V, U, kind, wrt;
+  // producer formats (ctc_amd_loss_grad_ex): element strides of the batch and time axes of logits and gradient (the
+  // token axis is contiguous) and their element types (0 = float32, 1 = bfloat16).  Everything else reads `logits`
+  // as contiguous float32 [B,T,V].
+  long xsb, xst, gsb, gst;
+  int xdtype, gdtype;
 };
+
+// bfloat16 <-> float32 (round to nearest even on the way back)
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  const unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
 
 // Device workspace layout.  UP = 64*NL lattice slots (label positions) per utterance, NL per lane.
 //   emis  [B][T][ERS]      : E[0..UP) = log2 p(label[i] at frame t) (NEG beyond label_length), [UP] = log2 p(blank),

@@ -190,8 +190,8 @@ __device__ __forceinline__ void restore_state(S_t &S, const SRow<KIND, NL> &r) {
   S.off = (double)r.tail.z + (double)r.tail.w;
 }
 
-template <int KIND, int NL, int DIR>
-__device__ __forceinline__ void init_labels(Side<KIND, NL, 1, DIR, true> &S, const Problem &p, int b, int lane, int ll) {
+template <int KIND, int NL, class S_t>
+__device__ __forceinline__ void init_labels(S_t &S, const Problem &p, int b, int lane, int ll) {
   const int32_t *lab = p.labels + (long)b * p.label_stride;
   auto tok = [&](int i) -> int { return (i >= 0 && i < ll) ? ((i < p.label_stride) ? lab[i] : p.blank) : -1 - (i < 0); };
 #pragma unroll
@@ -334,7 +334,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
   S.own_rows = (DIR == 0 ? alpha_ws : beta_ws) + (long)b * (T + 1) * L.SRS;
   S.oth_rows = (DIR == 0 ? beta_ws : alpha_ws) + (long)b * (T + 1) * L.SRS;
   S.off = 0.0;
-  init_labels<KIND, NL, DIR>(S, p, b, lane, ll);
+  init_labels<KIND, NL>(S, p, b, lane, ll);
   if constexpr (DIR == 0) {
     S.cx = 0.f;
   } else {
@@ -453,12 +453,12 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
 //   SIDE B classic (needs alpha[t+1] at t = BLK g + nv-1-d): step frames upward from alpha[BLK g], row after each step
 //   SIDE B simplified (needs a[t])                        : row before each step
 // ------------------------------------------------------------------------------------------------
-template <int KIND, int NL, int NH, int BLK, int SIDE>
+template <int KIND, int NL, int NH, int BLK, int SIDE, int XT>
 __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L, const float *__restrict__ alpha_ws,
                                               const float *__restrict__ beta_ws, float2 *__restrict__ stats_ws,
                                               Lds<KIND, NL, NH, BLK> &lds, const Geo<BLK> &geo, void *stamp_ws) {
   constexpr int RDIR = 1 - SIDE;  // direction of the recursion this wave runs
-  using S_t = Side<KIND, NL, 1, RDIR, true>;
+  using S_t = Side<KIND, NL, 1, RDIR, true, XT>;
   using LD = Lds<KIND, NL, NH, BLK>;
   S_t S;
   const int lane = threadIdx.x & 63;
@@ -470,7 +470,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
   S.ll = ll;
   S.off = 0.0;
   S.cx = NEG;
-  init_labels<KIND, NL, RDIR>(S, p, b, lane, ll);
+  init_labels<KIND, NL>(S, p, b, lane, ll);
   // checkpoints of the direction this wave runs: written by the OTHER side's main chain in phase 1
   const float *ck_rows = (RDIR == 0 ? alpha_ws : beta_ws) + (long)b * (T + 1) * L.SRS;
   float *dump = lds.dump[2 + SIDE];
@@ -478,7 +478,9 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
 
   {  // phase 1: nothing to recompute yet -- this wavefront works the E stage of its side (estage1)
     using SP = P1Split<BLK>;
-    S.xbase = p.logits + (long)b * T * 256;
+    S.xbase = XT != 2 ? p.logits + (long)b * p.xsb
+                      : reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(p.logits) + (long)b * p.xsb);
+    S.xst = p.xst;
     S.xs = lds.xcopy_r[SIDE];
     if (lane == 0) S.xs[256] = -6.0e29f;  // pad slot of the gather copy: "log 0" for label positions beyond label_length
     float2 *stats = stats_ws + (long)b * T;
@@ -558,13 +560,13 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
 // ------------------------------------------------------------------------------------------------
 // helper wavefront h of NH per side: positions d = h, h + NH, ... of every block (FPH = BLK / NH per block)
 // ------------------------------------------------------------------------------------------------
-template <int KIND, int NL, int NH, int BLK, int DIR>
+template <int KIND, int NL, int NH, int BLK, int DIR, int XT>
 __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, float2 *__restrict__ stats_ws,
                                            const float *__restrict__ d_loss, float *__restrict__ grad,
                                            Lds<KIND, NL, NH, BLK> &lds, const Geo<BLK> &geo, int h, void *stamp_ws) {
   constexpr int V = 256;
   constexpr int FPH = BLK / NH;
-  using S_t = Side<KIND, NL, 1, DIR, true>;
+  using S_t = Side<KIND, NL, 1, DIR, true, XT>;
   using LD = Lds<KIND, NL, NH, BLK>;
   S_t S;
   const int lane = threadIdx.x & 63;
@@ -575,12 +577,19 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
   int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
   if (ll > p.U) ll = 0;
   S.ll = ll;
-  S.xbase = p.logits + (long)b * T * V;
-  S.gbase = grad + (long)b * T * V;
+  if constexpr (XT != 2) {
+    S.xbase = p.logits + (long)b * p.xsb;
+    S.gbase = grad + (long)b * p.gsb;
+  } else {  // bfloat16 producer/consumer: the pointers are element-typed inside load_x / store_g
+    S.xbase = reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(p.logits) + (long)b * p.xsb);
+    S.gbase = reinterpret_cast<float *>(reinterpret_cast<unsigned short *>(grad) + (long)b * p.gsb);
+  }
+  S.xst = p.xst;
+  S.gst = p.gst;
   S.xs = lds.xcopy[DIR * NH + h];
   S.bins = lds.bins[DIR * NH + h];
   S.dl = d_loss ? d_loss[b] : 1.0f;
-  init_labels<KIND, NL, DIR>(S, p, b, lane, ll);
+  init_labels<KIND, NL>(S, p, b, lane, ll);
   if (lane == 0) S.xs[V] = -6.0e29f;  // pad slot of the gather copy: "log 0" for label positions beyond label_length
   float2 *stats = stats_ws + (long)b * T;
   float *dump = lds.dump[4 + DIR * NH + h];
@@ -741,7 +750,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
 }
 
 // Wavefront roles: 0 main A, 1 main B, 2 recompute for A, 3 recompute for B, then NH helpers of A, NH helpers of B.
-template <int KIND, int NL, int NH, int BLK>
+template <int KIND, int NL, int NH, int BLK, int XT>
 __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused5_kernel(Problem p, Layout L, float *__restrict__ alpha_ws,
                                                                     float *__restrict__ beta_ws,
                                                                     double *__restrict__ logp_ws,
@@ -761,14 +770,14 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused5_kernel(Problem p, La
     run_main<KIND, NL, NH, BLK, 1>(p, L, alpha_ws, beta_ws, logp_ws, loss, lds, geo, stamp_ws);
   } else if (w == 2) {
     __builtin_amdgcn_s_setprio(2);
-    run_recompute<KIND, NL, NH, BLK, 0>(p, L, alpha_ws, beta_ws, stats_ws, lds, geo, stamp_ws);
+    run_recompute<KIND, NL, NH, BLK, 0, XT>(p, L, alpha_ws, beta_ws, stats_ws, lds, geo, stamp_ws);
   } else if (w == 3) {
     __builtin_amdgcn_s_setprio(2);
-    run_recompute<KIND, NL, NH, BLK, 1>(p, L, alpha_ws, beta_ws, stats_ws, lds, geo, stamp_ws);
+    run_recompute<KIND, NL, NH, BLK, 1, XT>(p, L, alpha_ws, beta_ws, stats_ws, lds, geo, stamp_ws);
   } else if (w < 4 + NH) {
-    run_helper<KIND, NL, NH, BLK, 0>(p, L, stats_ws, d_loss, grad, lds, geo, w - 4, stamp_ws);
+    run_helper<KIND, NL, NH, BLK, 0, XT>(p, L, stats_ws, d_loss, grad, lds, geo, w - 4, stamp_ws);
   } else {
-    run_helper<KIND, NL, NH, BLK, 1>(p, L, stats_ws, d_loss, grad, lds, geo, w - 4 - NH, stamp_ws);
+    run_helper<KIND, NL, NH, BLK, 1, XT>(p, L, stats_ws, d_loss, grad, lds, geo, w - 4 - NH, stamp_ws);
   }
 }
 
@@ -778,8 +787,17 @@ template <int NL>
 static hipError_t launch5(const Problem &p, const Layout &L, float *a, float *b, double *lp, float2 *stats, float *loss,
                           const float *d_loss, float *grad, void *stamp, hipStream_t st) {
   constexpr int NH = 4, BLK = 12;
-  hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK>), dim3(p.B), dim3(64 * (4 + 2 * NH)), 0, st, p, L,
-                     a, b, lp, stats, loss, d_loss, grad, stamp);
+  const bool plain = p.xdtype == 0 && p.xst == p.V && p.gst == p.V;  // frame stride folded into the addressing
+  const dim3 grid(p.B), block(64 * (4 + 2 * NH));
+  if (plain)
+    hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, 0>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
+                       d_loss, grad, stamp);
+  else if (p.xdtype == 0)
+    hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, 1>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
+                       d_loss, grad, stamp);
+  else
+    hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, 2>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
+                       d_loss, grad, stamp);
   return hipGetLastError();
 }
 

@@ -146,7 +146,9 @@ struct Emis {
 // Rows are spilled in the layout the OTHER side's slots are aligned with:
 //   A -> rows[t] : slot i = (state_c(l=i) [, open(l=i+1)]), tail.x = state_c(l=UP)       (read by B)
 //   B -> rows[t] : slot i = (state_c(l=i+1) [, open(l=i+1)]), tail.x = state_c(l=0)      (read by A)
-template <int KIND, int NL, int VPL, int DIR, bool LOGITS>
+// XT: format of logits and gradient in HBM: 0 = contiguous float32 (frame stride V folded into the addressing),
+// 1 = float32 with run-time frame strides, 2 = bfloat16 with run-time frame strides.  Arithmetic is float32 either way.
+template <int KIND, int NL, int VPL, int DIR, bool LOGITS, int XT = 0>
 struct Side {
   static constexpr int V = 256 * VPL;
   // lattice state
@@ -157,8 +159,9 @@ struct Side {
   float mb[4 * VPL];  // 1.0 at this lane's element that is the blank column, else 0
   // geometry
   int lane, UP, len, ll, blank;
-  const float *xbase;   // logits of this utterance
-  float *gbase;         // gradient of this utterance
+  const float *xbase;   // logits of this utterance (XT = 1: really bfloat16)
+  float *gbase;         // gradient of this utterance (XT = 1: really bfloat16)
+  long xst = V, gst = V;  // element stride between frames (time-major producers: B*V)
   float *own_rows;      // spill rows this side writes
   const float *oth_rows;  // spill rows the other side writes
   int SRS;
@@ -179,9 +182,31 @@ struct Side {
   }
 
   __device__ __forceinline__ void load_x(float4 (&xr)[VPL], int t) const {
-    const float *row = xbase + (long)t * V + lane * 4;
+    if constexpr (XT != 2) {
+      const float *row = xbase + (long)t * (XT == 0 ? (long)V : xst) + lane * 4;
 #pragma unroll
-    for (int q = 0; q < VPL; ++q) xr[q] = *reinterpret_cast<const float4 *>(row + 256 * q);
+      for (int q = 0; q < VPL; ++q) xr[q] = *reinterpret_cast<const float4 *>(row + 256 * q);
+    } else {  // 4 bfloat16 = 8 bytes per lane; widening is a shift / mask
+      const unsigned short *row = reinterpret_cast<const unsigned short *>(xbase) + (long)t * xst + lane * 4;
+#pragma unroll
+      for (int q = 0; q < VPL; ++q) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(row + 256 * q);
+        xr[q] = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                            __uint_as_float(w.y & 0xffff0000u));
+      }
+    }
+  }
+  // one gradient row segment (4 values of this lane) in the output element type
+  __device__ __forceinline__ void store_g(int t, int q, float4 r) const {
+    if constexpr (XT != 2) {
+      *reinterpret_cast<float4 *>(gbase + (long)t * (XT == 0 ? (long)V : gst) + lane * 4 + 256 * q) = r;
+    } else {
+      unsigned short *row = reinterpret_cast<unsigned short *>(gbase) + (long)t * gst + lane * 4 + 256 * q;
+      uint2 w;
+      w.x = (unsigned)f32_to_bf16(r.x) | ((unsigned)f32_to_bf16(r.y) << 16);
+      w.y = (unsigned)f32_to_bf16(r.z) | ((unsigned)f32_to_bf16(r.w) << 16);
+      *reinterpret_cast<uint2 *>(row) = w;
+    }
   }
 
   // log-softmax statistics (tools.py:27-40): row max and log2 sum exp by DPP reductions
@@ -412,7 +437,6 @@ struct Side {
     }
     qb = wave_sum_dpp(qb);
     // (no wave barrier needed: LDS ops of one wave execute in order and may-alias accesses keep program order)
-    float *g = gbase + (long)t * V + lane * 4;
 #pragma unroll
     for (int q = 0; q < VPL; ++q) {
       const uint4 pu = *reinterpret_cast<const uint4 *>(bins + 256 * q + lane * 4);
@@ -428,7 +452,7 @@ struct Side {
       } else {
         r.x = -dl * pq.x; r.y = -dl * pq.y; r.z = -dl * pq.z; r.w = -dl * pq.w;
       }
-      *reinterpret_cast<float4 *>(g + 256 * q) = r;
+      store_g(t, q, r);
     }
     // (no wave barrier needed: LDS ops of one wave execute in order and may-alias accesses keep program order)
   }
@@ -482,9 +506,8 @@ struct Side {
 
   __device__ __forceinline__ void zero_rows(int t_from, int t_to) const {
     for (int t = t_from; t < t_to; ++t) {
-      float *g = gbase + (long)t * V + lane * 4;
 #pragma unroll
-      for (int q = 0; q < VPL; ++q) *reinterpret_cast<float4 *>(g + 256 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < VPL; ++q) store_g(t, q, make_float4(0.f, 0.f, 0.f, 0.f));
     }
   }
 };

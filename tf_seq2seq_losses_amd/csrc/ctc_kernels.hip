@@ -29,12 +29,17 @@ __global__ __launch_bounds__(256) void emit_kernel(Problem p, Layout L, float *_
   const int len = clampi(p.logit_length[b], 0, p.T);
   if (t >= len) return;  // padded frames are never read downstream
   const int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
-  const float *x = p.logits + row * (long)p.V;
   const int V = p.V;
+  // element accessor of this frame's row: float32 or bfloat16, any batch/time stride (producer formats)
+  const long xoff = (long)b * p.xsb + (long)t * p.xst;
+  const float *x = p.logits + xoff;                                                   // valid for float32 only
+  const unsigned short *xh = reinterpret_cast<const unsigned short *>(p.logits) + xoff;  // valid for bfloat16 only
+  const bool bf = p.xdtype != 0;
+  auto xat = [&](int k) -> float { return bf ? bf16_to_f32(xh[k]) : x[k]; };
 
   float mx = -INFINITY, sum = 0.f, log2sum = 0.f;
   if (p.wrt == 0) {
-    if ((V & 3) == 0) {
+    if (!bf && ((V | xoff) & 3) == 0) {
       for (int k = lane * 4; k < V; k += 256) {
         float4 v = *reinterpret_cast<const float4 *>(x + k);
         mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
@@ -47,10 +52,10 @@ __global__ __launch_bounds__(256) void emit_kernel(Problem p, Layout L, float *_
                fexp2((v.w - mref) * LOG2E);
       }
     } else {
-      for (int k = lane; k < V; k += 64) mx = fmaxf(mx, x[k]);
+      for (int k = lane; k < V; k += 64) mx = fmaxf(mx, xat(k));
       mx = wave_max(mx);
       const float mref = (mx == -INFINITY) ? 0.f : mx;
-      for (int k = lane; k < V; k += 64) sum += fexp2((x[k] - mref) * LOG2E);
+      for (int k = lane; k < V; k += 64) sum += fexp2((xat(k) - mref) * LOG2E);
     }
     sum = wave_sum(sum);
     log2sum = flog2(sum);  // -inf when the whole row is -inf: every emission becomes NEG below
@@ -65,14 +70,14 @@ __global__ __launch_bounds__(256) void emit_kernel(Problem p, Layout L, float *_
     float e = NEG;
     if (i < ll) {
       int tok = (i < p.label_stride) ? p.labels[(long)b * p.label_stride + i] : p.blank;
-      if (tok >= 0 && tok < V) e = fmaxf((x[tok] - mx) * LOG2E - log2sum, NEG);
+      if (tok >= 0 && tok < V) e = fmaxf((xat(tok) - mx) * LOG2E - log2sum, NEG);
       if (!(e == e)) e = NEG;
     }
     erow[i] = e;
   }
   if (lane == 0) {
     float bl = NEG;
-    if (p.blank >= 0 && p.blank < V) bl = fmaxf((x[p.blank] - mx) * LOG2E - log2sum, NEG);
+    if (p.blank >= 0 && p.blank < V) bl = fmaxf((xat(p.blank) - mx) * LOG2E - log2sum, NEG);
     if (!(bl == bl)) bl = NEG;
     erow[L.UP] = bl;
     // softmax(x)[k] = exp2((x[k] - mx) * log2e - log2sum); kept as two terms so that huge logits cancel exactly
@@ -380,13 +385,19 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
   if (row >= (long)p.B * p.T) return;
   const int b = (int)(row / p.T), t = (int)(row % p.T);
   const int V = p.V, UP = L.UP;
-  float *g = grad + row * (long)V;
+  // output row in the consumer's format: float32 or bfloat16, any batch/time stride
+  const long goff = (long)b * p.gsb + (long)t * p.gst;
+  float *g = grad + goff;                                                        // valid for float32 only
+  unsigned short *gh = reinterpret_cast<unsigned short *>(grad) + goff;           // valid for bfloat16 only
+  const bool gbf = p.gdtype != 0;
+  auto gput = [&](int k, float v) { if (gbf) gh[k] = f32_to_bf16(v); else g[k] = v; };
+  const bool gvec = !gbf && ((V | goff) & 3) == 0;
   const int len = clampi(p.logit_length[b], 0, p.T);
   const double lp = logp[b];
   if (t >= len || lp == -INFINITY) {
     // padded frames and infeasible samples: exactly zero (base_loss.py:283-298)
-    if ((V & 3) == 0) for (int k = lane * 4; k < V; k += 256) *reinterpret_cast<float4 *>(g + k) = make_float4(0.f, 0.f, 0.f, 0.f);
-    else for (int k = lane; k < V; k += 64) g[k] = 0.f;
+    if (gvec) for (int k = lane * 4; k < V; k += 256) *reinterpret_cast<float4 *>(g + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else for (int k = lane; k < V; k += 64) gput(k, 0.f);
     return;
   }
   int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
@@ -444,10 +455,13 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
   if (p.wrt == 0) {
     // g_x[k] = d_loss * (softmax(x)[k] * sum_k' post[k'] - post[k]), sum_k' post = 1 on a valid frame of a feasible
     // sample (TF autodiff of tools.py:37-39 applied to base_loss.py:150-153)
-    const float *x = p.logits + row * (long)V;
+    const long xoff = (long)b * p.xsb + (long)t * p.xst;
+    const float *x = p.logits + xoff;
+    const unsigned short *xh = reinterpret_cast<const unsigned short *>(p.logits) + xoff;
+    const bool bf = p.xdtype != 0;
     const float mx = emis[row * (long)L.ERS + UP + 1];
     const float l2s = emis[row * (long)L.ERS + UP + 2];
-    if ((V & 3) == 0) {
+    if (gvec && !bf && (xoff & 3) == 0) {
       for (int k = lane * 4; k < V; k += 256) {
         float4 v = *reinterpret_cast<const float4 *>(x + k);
         float4 q = *reinterpret_cast<const float4 *>(bin + k);
@@ -459,11 +473,14 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
         *reinterpret_cast<float4 *>(g + k) = r;
       }
     } else {
-      for (int k = lane; k < V; k += 64) g[k] = dl * (fexp2((x[k] - mx) * LOG2E - l2s) - bin[k]);
+      for (int k = lane; k < V; k += 64) {
+        const float xv = bf ? bf16_to_f32(xh[k]) : x[k];
+        gput(k, dl * (fexp2((xv - mx) * LOG2E - l2s) - bin[k]));
+      }
     }
   } else {
     // gradient w.r.t. log-probabilities: -posterior (base_loss.py:262-268)
-    for (int k = lane; k < V; k += 64) g[k] = -dl * bin[k];
+    for (int k = lane; k < V; k += 64) gput(k, -dl * bin[k]);
   }
 }
 

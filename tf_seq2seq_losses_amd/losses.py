@@ -50,7 +50,7 @@ def _blank(blank_index) -> int:
 def _verify_inputs(labels, x, label_length, logit_length):
     """base_loss.py:129-138 : same assertions, same exception type (AssertionError)."""
     assert x.dim() == 3
-    assert x.dtype == torch.float32
+    assert x.dtype in (torch.float32, torch.bfloat16)  # the reference takes float32 only; bfloat16 is an extension (DESIGN.md)
     assert labels.dim() == 2
     assert logit_length.dim() == 1
     assert label_length.dim() == 1
@@ -72,8 +72,8 @@ class _HessianContraction(torch.autograd.Function):
         # same product in O(T*L) memory.  CTC_AMD_HVP=dense keeps the materialised route (parity tests compare both).
         if os.environ.get("CTC_AMD_HVP", "") == "dense":
             _, _, hess = ops.hessian(kind, wrt, prep, want_grad=False)
-            return torch.einsum("btkuj,buj->btk", hess, v)
-        return ops.hvp(kind, wrt, prep, v)[2]
+            return torch.einsum("btkuj,buj->btk", hess, v.float()).to(x.dtype)
+        return ops.hvp(kind, wrt, prep, v)[2].to(x.dtype)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -88,7 +88,7 @@ class _CtcGradient(torch.autograd.Function):
     def forward(ctx, x, d_loss, kind, wrt, prep, grad_unit):
         ctx.kind, ctx.wrt, ctx.prep = kind, wrt, prep
         ctx.save_for_backward(x, d_loss, grad_unit)
-        return d_loss.reshape(-1, 1, 1) * grad_unit
+        return (d_loss.reshape(-1, 1, 1) * grad_unit).to(grad_unit.dtype)
 
     @staticmethod
     def backward(ctx, dd):
@@ -97,7 +97,7 @@ class _CtcGradient(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _HessianContraction.apply(x, dd * d_loss.reshape(-1, 1, 1), ctx.kind, ctx.wrt, ctx.prep)
         if ctx.needs_input_grad[1]:
-            gd = (dd * grad_unit).sum(dim=(1, 2))
+            gd = (dd.float() * grad_unit.float()).sum(dim=(1, 2)).to(d_loss.dtype)
         return gx, gd, None, None, None, None
 
 
@@ -127,7 +127,9 @@ def _ctc(kind_name: str, wrt: int, labels, x, label_length, logit_length, blank_
     logit_length = _as_tensor(logit_length, torch.int32)
     _verify_inputs(labels, x, label_length, logit_length)
     kind = ops.KINDS[kind_name]
-    prep = ops.Prepared(labels, x.detach(), label_length, logit_length, _blank(blank_index))
+    # logits keep the producer's format where the kernels read it directly (bfloat16, time-major views): no copy
+    prep = ops.Prepared(labels, x.detach(), label_length, logit_length, _blank(blank_index),
+                        keep_format=(wrt == _lib.WRT_LOGITS))
     return _CtcLoss.apply(x, kind, wrt, prep)
 
 

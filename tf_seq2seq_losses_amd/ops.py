@@ -24,13 +24,22 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
-class Prepared:
-    """Validated, contiguous device inputs of one call."""
+_DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 
-    def __init__(self, labels, x, label_length, logit_length, blank_index, U=None):
+
+class Prepared:
+    """Validated device inputs of one call.  By default the logits are made contiguous float32 [B,T,V]; with
+    keep_format=True a float32/bfloat16 tensor whose token axis is contiguous is passed as it is (time-major views,
+    bfloat16 activations: ctc_amd_loss_grad_ex) -- only loss_grad takes such inputs, the other entry points use plain()."""
+
+    def __init__(self, labels, x, label_length, logit_length, blank_index, U=None, keep_format=False):
         _require_gpu(x)
         dev = x.device
-        self.x = x.contiguous()
+        V = int(x.shape[2]) if x.dim() == 3 else 0
+        native = (keep_format and x.dim() == 3 and x.dtype in _DTYPES and x.numel() > 0 and x.stride(2) == 1
+                  and x.stride(0) >= V and x.stride(1) >= V)
+        self.native = bool(native) and not (x.dtype == torch.float32 and x.is_contiguous())
+        self.x = x if native else x.to(torch.float32).contiguous()
         self.labels = labels.to(device=dev, dtype=torch.int32).contiguous()
         self.label_length = label_length.to(device=dev, dtype=torch.int32).contiguous()
         self.logit_length = logit_length.to(device=dev, dtype=torch.int32).contiguous()
@@ -42,7 +51,18 @@ class Prepared:
         self.U = self.stride if U is None else int(U)
         self.device = dev
 
+    def plain(self) -> "Prepared":
+        """The same inputs with contiguous float32 logits (Hessian, HVP and alpha/beta read that format only)."""
+        if not self.native:
+            return self
+        q = Prepared.__new__(Prepared)
+        q.__dict__.update(self.__dict__)
+        q.x = self.x.to(torch.float32).contiguous()
+        q.native = False
+        return q
+
     def common(self, kind: int, wrt: int):
+        assert not self.native, "this entry point takes contiguous float32 logits: use Prepared.plain()"
         return (kind, wrt, _ptr(self.x), _ptr(self.labels), self.stride, _ptr(self.label_length),
                 _ptr(self.logit_length), self.blank, self.B, self.T, self.V, self.U)
 
@@ -60,21 +80,32 @@ def loss_grad(kind: int, wrt: int, p: Prepared, want_grad: bool, d_loss: Optiona
               workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     lib = _lib.load()
     loss = torch.empty(p.B, dtype=torch.float32, device=p.device)
-    grad = torch.empty((p.B, p.T, p.V), dtype=torch.float32, device=p.device) if want_grad else None
+    if p.native:  # the gradient goes back in the producer's format: same element type, same strides
+        grad = torch.empty_strided(p.x.shape, p.x.stride(), dtype=p.x.dtype, device=p.device) if want_grad else None
+    else:
+        grad = torch.empty((p.B, p.T, p.V), dtype=torch.float32, device=p.device) if want_grad else None
     if p.B == 0:
         return loss, grad
     ws = workspace if workspace is not None else _workspace(_lib.WS_LOSS_GRAD, kind, p)
     if d_loss is not None:
         d_loss = d_loss.to(device=p.device, dtype=torch.float32).contiguous()
     with torch.cuda.device(p.device):
-        rc = lib.ctc_amd_loss_grad(*p.common(kind, wrt), _ptr(loss), _ptr(grad), _ptr(d_loss),
-                                   ws.data_ptr(), ws.numel(), _stream(p.device))
+        if p.native:
+            dt = _DTYPES[p.x.dtype]
+            rc = lib.ctc_amd_loss_grad_ex(kind, wrt, _ptr(p.x), dt, p.x.stride(0), p.x.stride(1), _ptr(p.labels), p.stride,
+                                          _ptr(p.label_length), _ptr(p.logit_length), p.blank, p.B, p.T, p.V, p.U,
+                                          _ptr(loss), _ptr(grad), dt, p.x.stride(0), p.x.stride(1), _ptr(d_loss),
+                                          ws.data_ptr(), ws.numel(), _stream(p.device))
+        else:
+            rc = lib.ctc_amd_loss_grad(*p.common(kind, wrt), _ptr(loss), _ptr(grad), _ptr(d_loss),
+                                       ws.data_ptr(), ws.numel(), _stream(p.device))
     _lib.check(rc, "ctc_amd_loss_grad")
     return loss, grad
 
 
 def alpha_beta(kind: int, wrt: int, p: Prepared):
     lib = _lib.load()
+    p = p.plain()
     L = p.U + 1
     shape = (p.B, p.T + 1, L, 2) if kind == _lib.CLASSIC else (p.B, p.T + 1, L)
     loss = torch.empty(p.B, dtype=torch.float32, device=p.device)
@@ -92,6 +123,7 @@ def alpha_beta(kind: int, wrt: int, p: Prepared):
 
 def hessian(kind: int, wrt: int, p: Prepared, want_grad: bool = True):
     lib = _lib.load()
+    p = p.plain()
     loss = torch.empty(p.B, dtype=torch.float32, device=p.device)
     grad = torch.empty((p.B, p.T, p.V), dtype=torch.float32, device=p.device) if want_grad else None
     hess = torch.empty((p.B, p.T, p.V, p.T, p.V), dtype=torch.float32, device=p.device)
@@ -110,6 +142,7 @@ def hessian(kind: int, wrt: int, p: Prepared, want_grad: bool = True):
 def hvp(kind: int, wrt: int, p: Prepared, vec: torch.Tensor, want_grad: bool = False):
     """out[b,t,k] = sum_{t2,k2} H[b,t,k,t2,k2] vec[b,t2,k2] through ctc_amd_hvp (no [B,T,V,T,V] tensor)."""
     lib = _lib.load()
+    p = p.plain()
     assert tuple(vec.shape) == (p.B, p.T, p.V), f"vec must be [B,T,V] = {(p.B, p.T, p.V)}, got {tuple(vec.shape)}"
     vec = vec.to(device=p.device, dtype=torch.float32).contiguous()
     loss = torch.empty(p.B, dtype=torch.float32, device=p.device)
