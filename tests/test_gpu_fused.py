@@ -99,3 +99,28 @@ def test_fused_neg_inf_logits(kind):
     ll = np.array([5, 3, 5], dtype=np.int32)
     tl = np.array([30, 30, 22], dtype=np.int32)
     _check(kind, logits, labels, ll, tl)
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_loss_only_stops_at_the_meeting_point(kind):
+    """grad == NULL (forward_fn alone, base_loss.py:140-155): fused5 runs phase 1 only; the loss must be the one the
+    loss+gradient call returns, including +inf for infeasible samples and the ragged/empty cases."""
+    from tf_seq2seq_losses_amd import ops, _lib
+    rng = np.random.default_rng(9)
+    B, T, V, U = 9, 131, 256, 60
+    logits = rng.standard_normal((B, T, V)).astype(np.float32)
+    labels = rng.integers(1, V, (B, U)).astype(np.int32)
+    ll = np.array([60, 0, 13, 60, 1, 33, 60, 7, 20], np.int32)
+    tl = np.array([131, 131, 40, 50, 0, 131, 12, 99, 131], np.int32)  # 50 < 60 and 12 < 60: infeasible
+    dev = torch.device("cuda:0")
+    p = ops.Prepared(torch.from_numpy(labels).to(dev), torch.from_numpy(logits).to(dev), torch.from_numpy(ll).to(dev),
+                     torch.from_numpy(tl).to(dev), 0)
+    assert _lib.pipeline_name(ops.KINDS[kind], _lib.WRT_LOGITS, B, T, V, U, False) == "fused5"
+    l_only, g_none = ops.loss_grad(ops.KINDS[kind], _lib.WRT_LOGITS, p, False)
+    l_both, _ = ops.loss_grad(ops.KINDS[kind], _lib.WRT_LOGITS, p, True)
+    assert g_none is None
+    assert torch.equal(l_only, l_both)
+    rl, _ = C.loss_grad(kind, labels, logits, ll, tl, 0, want_grad=False)
+    fin = np.isfinite(rl)
+    assert np.array_equal(np.isfinite(l_only.cpu().numpy()), fin)
+    assert np.abs(l_only.cpu().numpy()[fin] - rl[fin]).max() < TOL * max(1.0, np.abs(rl[fin]).max())

@@ -105,8 +105,10 @@ static const char *select_pipeline(const ctc::Problem &p, const ctc::Layout &L, 
   const bool force_v1 = pipe && pipe[0] == 'v' && pipe[1] == '1';
   const bool force_f2 = pipe && pipe[0] == 'f' && pipe[5] == '2';
   const bool force_f4 = pipe && pipe[0] == 'f' && pipe[5] == '4';
-  if (!want_grad || force_v1) return "v1";
+  if (force_v1) return "v1";
+  // loss only (grad == NULL): fused5 stops at the meeting point of its two chains; the other fused tiers need a gradient
   if (!force_f2 && !force_f4 && ctc::fused5_eligible(p, L)) return "fused5";
+  if (!want_grad) return "v1";
   if (!force_f2 && ctc::fused4_eligible(p, L)) return "fused4";
   if (ctc::fused_eligible(p, L)) return "fused2";
   return "v1";

@@ -317,7 +317,7 @@ template <int KIND, int NL, int NH, int BLK, int DIR>
 __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, float *__restrict__ alpha_ws,
                                          float *__restrict__ beta_ws, double *__restrict__ logp_ws,
                                          float *__restrict__ loss, Lds<KIND, NL, NH, BLK> &lds, const Geo<BLK> &geo,
-                                         void *stamp_ws) {
+                                         void *stamp_ws, bool want_grad) {
   using S_t = Side<KIND, NL, 1, DIR, true>;
   using LD = Lds<KIND, NL, NH, BLK>;
   S_t S;
@@ -399,6 +399,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
     lds.feasible = (dlogp != -INFINITY);
   }
   __syncthreads();
+  if (!want_grad) return;  // loss only (grad == NULL): every role leaves here, after the same barriers
   if (dlogp == -INFINITY) dlogp = 0.0;  // infeasible: keep the barrier schedule; the helpers write zeros instead
 
   // ================= phase 2: everything from LDS =================
@@ -456,7 +457,8 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
 template <int KIND, int NL, int NH, int BLK, int SIDE, int XT>
 __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L, const float *__restrict__ alpha_ws,
                                               const float *__restrict__ beta_ws, float2 *__restrict__ stats_ws,
-                                              Lds<KIND, NL, NH, BLK> &lds, const Geo<BLK> &geo, void *stamp_ws) {
+                                              Lds<KIND, NL, NH, BLK> &lds, const Geo<BLK> &geo, void *stamp_ws,
+                                              bool want_grad) {
   constexpr int RDIR = 1 - SIDE;  // direction of the recursion this wave runs
   using S_t = Side<KIND, NL, 1, RDIR, true, XT>;
   using LD = Lds<KIND, NL, NH, BLK>;
@@ -489,6 +491,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
   STAMP(st.phase1_done());
   __syncthreads();
   __syncthreads();
+  if (!want_grad) return;
 
   const int nb = geo.nblocks(2, SIDE);
   auto ck_index = [&](int j) -> int {
@@ -631,6 +634,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
   // ================= meeting point =================
   __syncthreads();
   __syncthreads();
+  if (grad == nullptr) return;  // loss only
   const bool feasible = lds.feasible != 0;
 
   // ================= phase 2: E stage (statistics from the record), G stage three blocks behind =================
@@ -764,16 +768,16 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused5_kernel(Problem p, La
   geo.init(clampi(p.logit_length[blockIdx.x], 0, p.T));
   if (w == 0) {
     __builtin_amdgcn_s_setprio(3);  // the sequential chains win issue arbitration against co-resident helpers
-    run_main<KIND, NL, NH, BLK, 0>(p, L, alpha_ws, beta_ws, logp_ws, loss, lds, geo, stamp_ws);
+    run_main<KIND, NL, NH, BLK, 0>(p, L, alpha_ws, beta_ws, logp_ws, loss, lds, geo, stamp_ws, grad != nullptr);
   } else if (w == 1) {
     __builtin_amdgcn_s_setprio(3);
-    run_main<KIND, NL, NH, BLK, 1>(p, L, alpha_ws, beta_ws, logp_ws, loss, lds, geo, stamp_ws);
+    run_main<KIND, NL, NH, BLK, 1>(p, L, alpha_ws, beta_ws, logp_ws, loss, lds, geo, stamp_ws, grad != nullptr);
   } else if (w == 2) {
     __builtin_amdgcn_s_setprio(2);
-    run_recompute<KIND, NL, NH, BLK, 0, XT>(p, L, alpha_ws, beta_ws, stats_ws, lds, geo, stamp_ws);
+    run_recompute<KIND, NL, NH, BLK, 0, XT>(p, L, alpha_ws, beta_ws, stats_ws, lds, geo, stamp_ws, grad != nullptr);
   } else if (w == 3) {
     __builtin_amdgcn_s_setprio(2);
-    run_recompute<KIND, NL, NH, BLK, 1, XT>(p, L, alpha_ws, beta_ws, stats_ws, lds, geo, stamp_ws);
+    run_recompute<KIND, NL, NH, BLK, 1, XT>(p, L, alpha_ws, beta_ws, stats_ws, lds, geo, stamp_ws, grad != nullptr);
   } else if (w < 4 + NH) {
     run_helper<KIND, NL, NH, BLK, 0, XT>(p, L, stats_ws, d_loss, grad, lds, geo, w - 4, stamp_ws);
   } else {
