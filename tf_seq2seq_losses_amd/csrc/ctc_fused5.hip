@@ -200,7 +200,7 @@ __device__ __forceinline__ void init_labels(S_t &S, const Problem &p, int b, int
     int tk = tok(i);
     S.norep[j] = (i == 0) || tk != tok(i - 1);
     S.norep_next[j] = tok(i + 1) != tk;
-    S.tokoff[j] = 4 * ((tk >= 0 && tk < 256 && tk != p.blank) ? tk : 256);
+    S.tokoff[j] = 4 * ((tk >= 0 && tk < p.V && tk < 256 && tk != p.blank) ? tk : 256);
     S.c[j] = NEG;
     S.o[j] = NEG;
   }
@@ -483,6 +483,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
     S.xbase = XT != 2 ? p.logits + (long)b * p.xsb
                       : reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(p.logits) + (long)b * p.xsb);
     S.xst = p.xst;
+    S.Vr = p.V;
     S.xs = lds.xcopy_r[SIDE];
     if (lane == 0) S.xs[256] = -6.0e29f;  // pad slot of the gather copy: "log 0" for label positions beyond label_length
     float2 *stats = stats_ws + (long)b * T;
@@ -589,6 +590,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
   }
   S.xst = p.xst;
   S.gst = p.gst;
+  S.Vr = p.V;
   S.xs = lds.xcopy[DIR * NH + h];
   S.bins = lds.bins[DIR * NH + h];
   S.dl = d_loss ? d_loss[b] : 1.0f;
@@ -791,7 +793,7 @@ template <int NL>
 static hipError_t launch5(const Problem &p, const Layout &L, float *a, float *b, double *lp, float2 *stats, float *loss,
                           const float *d_loss, float *grad, void *stamp, hipStream_t st) {
   constexpr int NH = 4, BLK = 12;
-  const bool plain = p.xdtype == 0 && p.xst == p.V && p.gst == p.V;  // frame stride folded into the addressing
+  const bool plain = p.xdtype == 0 && p.V == 256 && p.xst == 256 && p.gst == 256;  // frame stride folded into the addressing
   const dim3 grid(p.B), block(64 * (4 + 2 * NH));
   if (plain)
     hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, 0>), grid, block, 0, st, p, L, a, b, lp, stats, loss,

@@ -162,6 +162,7 @@ struct Side {
   const float *xbase;   // logits of this utterance (XT = 1: really bfloat16)
   float *gbase;         // gradient of this utterance (XT = 1: really bfloat16)
   long xst = V, gst = V;  // element stride between frames (time-major producers: B*V)
+  int Vr = V;             // XT != 0: actual vocabulary size <= V (multiple of 4); lanes beyond it read -inf, write nothing
   float *own_rows;      // spill rows this side writes
   const float *oth_rows;  // spill rows the other side writes
   int SRS;
@@ -182,15 +183,23 @@ struct Side {
   }
 
   __device__ __forceinline__ void load_x(float4 (&xr)[VPL], int t) const {
-    if constexpr (XT != 2) {
-      const float *row = xbase + (long)t * (XT == 0 ? (long)V : xst) + lane * 4;
+    if constexpr (XT == 0) {
+      const float *row = xbase + (long)t * V + lane * 4;
 #pragma unroll
       for (int q = 0; q < VPL; ++q) xr[q] = *reinterpret_cast<const float4 *>(row + 256 * q);
+    } else if constexpr (XT == 1) {
+      const float *row = xbase + (long)t * xst + lane * 4;
+#pragma unroll
+      for (int q = 0; q < VPL; ++q) {
+        xr[q] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);  // tokens beyond the vocabulary: log 0
+        if (lane * 4 + 256 * q < Vr) xr[q] = *reinterpret_cast<const float4 *>(row + 256 * q);
+      }
     } else {  // 4 bfloat16 = 8 bytes per lane; widening is a shift / mask
       const unsigned short *row = reinterpret_cast<const unsigned short *>(xbase) + (long)t * xst + lane * 4;
 #pragma unroll
       for (int q = 0; q < VPL; ++q) {
-        const uint2 w = *reinterpret_cast<const uint2 *>(row + 256 * q);
+        uint2 w = make_uint2(0xff80ff80u, 0xff80ff80u);  // bfloat16 -inf
+        if (lane * 4 + 256 * q < Vr) w = *reinterpret_cast<const uint2 *>(row + 256 * q);
         xr[q] = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
                             __uint_as_float(w.y & 0xffff0000u));
       }
@@ -198,14 +207,16 @@ struct Side {
   }
   // one gradient row segment (4 values of this lane) in the output element type
   __device__ __forceinline__ void store_g(int t, int q, float4 r) const {
-    if constexpr (XT != 2) {
-      *reinterpret_cast<float4 *>(gbase + (long)t * (XT == 0 ? (long)V : gst) + lane * 4 + 256 * q) = r;
+    if constexpr (XT == 0) {
+      *reinterpret_cast<float4 *>(gbase + (long)t * V + lane * 4 + 256 * q) = r;
+    } else if constexpr (XT == 1) {
+      if (lane * 4 + 256 * q < Vr) *reinterpret_cast<float4 *>(gbase + (long)t * gst + lane * 4 + 256 * q) = r;
     } else {
       unsigned short *row = reinterpret_cast<unsigned short *>(gbase) + (long)t * gst + lane * 4 + 256 * q;
       uint2 w;
       w.x = (unsigned)f32_to_bf16(r.x) | ((unsigned)f32_to_bf16(r.y) << 16);
       w.y = (unsigned)f32_to_bf16(r.z) | ((unsigned)f32_to_bf16(r.w) << 16);
-      *reinterpret_cast<uint2 *>(row) = w;
+      if (lane * 4 + 256 * q < Vr) *reinterpret_cast<uint2 *>(row) = w;
     }
   }
 

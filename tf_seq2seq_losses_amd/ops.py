@@ -9,6 +9,7 @@ import torch
 from . import _lib
 
 KINDS = {"classic": _lib.CLASSIC, "simplified": _lib.SIMPLIFIED}
+FUSED_MAX_U = 128  # label positions the fused loss+gradient kernels hold in registers (two per lane)
 
 
 def _require_gpu(t: torch.Tensor) -> None:
@@ -47,8 +48,14 @@ class Prepared:
         self.B, self.T, self.V = (int(s) for s in x.shape)
         self.stride = int(self.labels.shape[1])
         # static bound on the label length: identical results to the reference's dynamic max(label_length)
-        # (base_loss.py:482-486) without a device->host sync
-        self.U = self.stride if U is None else int(U)
+        # (base_loss.py:482-486) without a device->host sync.  Only when the label tensor is wider than the fused
+        # kernels' 128 positions (e.g. padded to the frame count, tests/common.py:89-94) is the maximum fetched -- one
+        # small sync that lets such batches take the fused path when their labels are in fact short.
+        if U is None:
+            U = self.stride
+            if U > FUSED_MAX_U and self.label_length.numel() > 0:
+                U = max(0, min(U, int(self.label_length.max().item())))
+        self.U = int(U)
         self.device = dev
 
     def plain(self) -> "Prepared":
