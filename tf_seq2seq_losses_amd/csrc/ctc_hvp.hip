@@ -115,37 +115,47 @@ __global__ __launch_bounds__(64) void tscan_kernel(Problem p, Layout L, const fl
   const float *derows = demis + (long)b * T * L.ERS;
 
   struct Row { float c[NL], o[NL], cx; double off; };  // a value row in the chain's NATIVE layout
-  auto load_native = [&](Row &r, int t) {
-    const float *q = vrows + (long)t * L.SRS;
-    float a[NL], bb[NL];
+  struct Em { float y[NL], bl, dy[NL], dbl; };
+  // One step's inputs as loaded (conversions need DPP and therefore the data: they are done at use, so that PF steps of
+  // loads can be in flight).  Wave-uniform values come through vector loads as well (vz: an opaque zero), which keeps
+  // them on vmcnt with the rest instead of serialising on the scalar cache.
+  struct Raw { float a[NL], bb[NL], tl, oh, ol, y[NL], bl, dy[NL], dbl; };
+  int vz;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+  auto load_row_raw = [&](Raw &w, int trow) {
+    const float *q = vrows + (long)trow * L.SRS;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int i = lane * NL + j;
-      if constexpr (KIND == 0) { float2 v = *reinterpret_cast<const float2 *>(q + 2 * i); a[j] = v.x; bb[j] = v.y; }
-      else { a[j] = q[i]; bb[j] = NEG; }
+      if constexpr (KIND == 0) { float2 v = *reinterpret_cast<const float2 *>(q + 2 * i); w.a[j] = v.x; w.bb[j] = v.y; }
+      else { w.a[j] = q[i]; w.bb[j] = NEG; }
     }
-    const float tl = q[tailpos];
-    if (dir == 0) {  // alpha rows are stored in native layout
-#pragma unroll
-      for (int j = 0; j < NL; ++j) { r.c[j] = a[j]; r.o[j] = bb[j]; }
-      r.cx = tl;
-    } else {  // beta rows: slot i = state l = i+1, tail = l = 0  ->  native: slot i = state_c(l = i), cx = l = UP
-#pragma unroll
-      for (int j = NL - 1; j > 0; --j) r.c[j] = a[j - 1];
-      r.c[0] = from_prev_lane(a[NL - 1], tl);
-      r.cx = readlane_f(a[NL - 1], 63);
-#pragma unroll
-      for (int j = 0; j < NL; ++j) r.o[j] = bb[j];
-    }
-    r.off = (double)q[tailpos + 2] + (double)q[tailpos + 3];
+    w.tl = q[tailpos + vz]; w.oh = q[tailpos + 2 + vz]; w.ol = q[tailpos + 3 + vz];
   };
-  struct Em { float y[NL], bl, dy[NL], dbl; };
-  auto load_em = [&](Em &e, int t) {
+  auto load_raw = [&](Raw &w, int k) {  // inputs of step k: emissions of the frame it consumes, the value row it produces
+    const int kk = k < len ? k : len - 1;
+    const int t = dir == 0 ? kk : len - 1 - kk;
+    load_row_raw(w, dir == 0 ? t + 1 : t);
     const float *q = erows + (long)t * L.ERS, *dq = derows + (long)t * L.ERS;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) { e.y[j] = q[lane * NL + j]; e.dy[j] = dq[lane * NL + j]; }
-    e.bl = q[UP];
-    e.dbl = dq[UP];
+    for (int j = 0; j < NL; ++j) { w.y[j] = q[lane * NL + j]; w.dy[j] = dq[lane * NL + j]; }
+    w.bl = q[UP + vz];
+    w.dbl = dq[UP + vz];
+  };
+  auto to_row = [&](const Raw &w, Row &r) {
+    if (dir == 0) {  // alpha rows are stored in native layout
+#pragma unroll
+      for (int j = 0; j < NL; ++j) { r.c[j] = w.a[j]; r.o[j] = w.bb[j]; }
+      r.cx = w.tl;
+    } else {  // beta rows: slot i = state l = i+1, tail = l = 0  ->  native: slot i = state_c(l = i), cx = l = UP
+#pragma unroll
+      for (int j = NL - 1; j > 0; --j) r.c[j] = w.a[j - 1];
+      r.c[0] = from_prev_lane(w.a[NL - 1], w.tl);
+      r.cx = readlane_f(w.a[NL - 1], 63);
+#pragma unroll
+      for (int j = 0; j < NL; ++j) r.o[j] = w.bb[j];
+    }
+    r.off = (double)w.oh + (double)w.ol;
   };
   // tangent state (natural-log units), native layout
   float dc[NL], dob[NL], dcx = 0.f;
@@ -179,20 +189,34 @@ __global__ __launch_bounds__(64) void tscan_kernel(Problem p, Layout L, const fl
   // 1 - w so the pair sums to one exactly: tangents carry a large common component (the running sum of the blank
   // direction) that must pass through unchanged, d = d2 + w (d1 - d2).  Unreachable results carry no weight.
   auto w = [](float arg, float res) -> float { return res > NEG_THR ? fminf(fexp2(arg - res), 1.0f) : 0.f; };
-  Row prev, next;
-  load_native(prev, dir == 0 ? 0 : len);
+  Row prev;
+  {
+    Raw w0;
+    load_row_raw(w0, dir == 0 ? 0 : len);
+    to_row(w0, prev);
+  }
   store_tangent(dir == 0 ? 0 : len);  // boundary rows have zero tangent
+  // steps of look-ahead (register ring, statically indexed: the loop is unrolled by TPF); shallower for long labels, whose
+  // rows fill the register file
+  constexpr int TPF = NL <= 2 ? 8 : (NL == 4 ? 4 : (NL == 8 ? 2 : 1));
+  Raw ring[TPF];
   if (len > 0) {
-    Em e, en;
-    load_em(e, dir == 0 ? 0 : len - 1);
-    load_native(next, dir == 0 ? 1 : len - 1);
-    for (int k = 0; k < len; ++k) {
-      const int t = dir == 0 ? k : len - 1 - k;           // frame consumed
-      const int tres = dir == 0 ? t + 1 : t;              // row produced
-      const int kn = (k + 1 < len) ? k + 1 : k;
-      Row nn;
-      load_em(en, dir == 0 ? kn : len - 1 - kn);          // prefetch the next step
-      load_native(nn, dir == 0 ? kn + 1 : len - 1 - kn);
+    static_for<0, TPF>([&](auto D) { load_raw(ring[decltype(D)::value], decltype(D)::value); });
+    int k0 = 0;
+    auto step = [&](auto D) __attribute__((always_inline)) {
+      constexpr int d = decltype(D)::value;
+      const int k = k0 + d;
+      {
+        const int t = dir == 0 ? k : len - 1 - k;           // frame consumed
+        const int tres = dir == 0 ? t + 1 : t;              // row produced
+        Row next;
+        Em e;
+        to_row(ring[d], next);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { e.y[j] = ring[d].y[j]; e.dy[j] = ring[d].dy[j]; }
+        e.bl = ring[d].bl;
+        e.dbl = ring[d].dbl;
+        load_raw(ring[d], k + TPF);                         // refill the slot (clamped at the end)
       const float doff = (float)(prev.off - next.off);    // rows carry different renormalisation offsets
       if constexpr (KIND == 0) {
         if (dir == 0) {
@@ -262,11 +286,14 @@ __global__ __launch_bounds__(64) void tscan_kernel(Problem p, Layout L, const fl
           dcx += e.dbl;
         }
       }
-      store_tangent(tres);
-      prev = next;
-      next = nn;
-      e = en;
-    }
+        store_tangent(tres);
+        prev = next;
+      }
+    };
+    for (; k0 + TPF <= len; k0 += TPF) static_for<0, TPF>(step);
+    static_for<0, TPF>([&](auto D) {
+      if (k0 + decltype(D)::value < len) step(D);
+    });
   }
   if (dir == 0) {
     // dlogP = tangent of alpha[len, label_length] (classic: of closed (+) open there)
