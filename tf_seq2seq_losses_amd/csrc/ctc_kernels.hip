@@ -97,7 +97,7 @@ struct ERow {
 };
 
 template <int NL>
-__device__ __forceinline__ void load_erow(ERow<NL> &r, const float *__restrict__ base, int lane, int UP) {
+__device__ __forceinline__ void load_erow(ERow<NL> &r, const float *__restrict__ base, int lane, int UP, int vz) {
   const float *p = base + lane * NL;
   if constexpr (NL == 1) {
     r.y[0] = p[0];
@@ -111,7 +111,9 @@ __device__ __forceinline__ void load_erow(ERow<NL> &r, const float *__restrict__
       r.y[4 * q] = v.x; r.y[4 * q + 1] = v.y; r.y[4 * q + 2] = v.z; r.y[4 * q + 3] = v.w;
     }
   }
-  r.bl = base[UP];
+  // the blank emission is wave-uniform; fetched as a VECTOR load (vz = opaque zero): a scalar load returns out of
+  // order, so its use forces lgkmcnt(0), i.e. a wait for the youngest prefetch of the ring instead of the oldest
+  r.bl = base[UP + vz];
 }
 
 // store NL consecutive (a, b) pairs of this lane
@@ -319,15 +321,17 @@ __device__ __forceinline__ void scan_body(const Problem &p, const Layout &L, con
   auto out_row = [&](int k) -> float * { return rows + (long)(DIR == 0 ? k + 1 : len - 1 - k) * L.SRS; };
 
   if (len > 0) {
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
     ERow<NL> buf[PF];
 #pragma unroll
-    for (int d = 0; d < PF; ++d) load_erow<NL>(buf[d], erow_ptr(d), lane, UP);
+    for (int d = 0; d < PF; ++d) load_erow<NL>(buf[d], erow_ptr(d), lane, UP, vz);
     int k0 = 0;
     for (; k0 + PF <= len; k0 += PF) {
 #pragma unroll
       for (int d = 0; d < PF; ++d) {
         S.step(buf[d]);
-        load_erow<NL>(buf[d], erow_ptr(k0 + d + PF), lane, UP);  // clamped: re-reads the last row near the end
+        load_erow<NL>(buf[d], erow_ptr(k0 + d + PF), lane, UP, vz);  // clamped: re-reads the last row near the end
         if (d == RENORM - 1) S.renorm();
 #ifndef CTC_EXPERIMENT_NO_STORE
         S.store_row(out_row(k0 + d), lane, UP);
