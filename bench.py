@@ -70,9 +70,38 @@ def cpu_baseline(kind, host, budget_s=15.0):
         dt += run(n)
         reps += 1
     dt /= reps
-    return dict(value=n / dt, unit="utterances/s", cores=threads, kind="port",
-                sample=f"oracle/ctc_oracle.c (C restatement of the reference's log-space alpha/beta + gradient, float32, "
-                       f"OpenMP {threads} threads of {cores} host cores) loss+grad on the first {n} utterances of the workload, mean of {reps} runs of {dt:.2f} s")
+    out = dict(value=n / dt, unit="utterances/s", cores=threads, kind="port",
+               sample=f"oracle/ctc_oracle.c (C restatement of the reference's log-space alpha/beta + gradient, float32, "
+                      f"OpenMP {threads} threads of {cores} host cores) loss+grad on the first {n} utterances of the workload, mean of {reps} runs of {dt:.2f} s")
+    # beside it: the same port on ONE thread, and an independent, widely used CPU implementation
+    # (torch.nn.functional.ctc_loss forward + backward incl. log_softmax, float32, all host threads; classic lattice only)
+    m1 = min(B, 4)
+    t0 = time.perf_counter()
+    C.loss_grad(kind, host["labels"][:m1], host["logits"][:m1], host["label_length"][:m1], host["logit_length"][:m1], 0,
+                precision="f32", want_grad=True, n_threads=1)
+    out["single_thread"] = dict(value=m1 / (time.perf_counter() - t0), unit="utterances/s", sample=f"{m1} utterances, 1 thread")
+    if kind == "classic":
+        mt = min(B, 64)
+        old_threads = torch.get_num_threads()
+        torch.set_num_threads(threads)
+        x = torch.from_numpy(host["logits"][:mt]).requires_grad_(True)
+        lab = torch.from_numpy(host["labels"][:mt]).long()
+        il = torch.from_numpy(host["logit_length"][:mt]).long()
+        tl = torch.from_numpy(host["label_length"][:mt]).long()
+
+        def torch_run():
+            t0 = time.perf_counter()
+            lp = torch.log_softmax(x, dim=2).transpose(0, 1)
+            loss = torch.nn.functional.ctc_loss(lp, lab, il, tl, blank=0, reduction="sum", zero_infinity=False)
+            torch.autograd.grad(loss, x)
+            return time.perf_counter() - t0
+        torch_run()
+        dtt = min(torch_run() for _ in range(3))
+        out["torch_ctc_cpu"] = dict(value=mt / dtt, unit="utterances/s",
+                                    sample=f"torch.nn.functional.ctc_loss + log_softmax forward+backward, float32, "
+                                           f"{torch.get_num_threads()} threads, {mt} utterances, best of 3")
+        torch.set_num_threads(old_threads)
+    return out
 
 
 def main():
