@@ -282,7 +282,7 @@ def main():
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_ms_per_launch": kernel_ms, "device_ms_per_step_incl_reduction": dev_ms_per_step},
         }
-        if not args.no_cpu_baseline and not args.hessian:
+        if not args.no_cpu_baseline and not args.hessian and world == 1:  # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(args.kind, host)
         else:
             out["cpu_baseline"] = None
