@@ -76,8 +76,14 @@ def test_bfloat16_logits_and_gradient(kind, B, T, V, U, time_major):
     l0, g0 = _call(kind, labels, xb.float().contiguous(), ll, tl)   # plain float32 call on the same values
     l1, g1 = _call(kind, labels, xb, ll, tl)
     assert g1.dtype == torch.bfloat16 and g1.stride() == xb.stride()
-    assert torch.equal(l0, l1)                                        # same float32 arithmetic after widening
-    assert torch.equal(g1, g0.to(torch.bfloat16))                     # the float32 gradient, rounded once
+    from tf_seq2seq_losses_amd import _lib
+    same_kernel = V % 4 == 0 or _lib.pipeline_name(0, 0, B, T, V, U, True) == "v1"
+    if same_kernel:  # both calls run the same kernel: same float32 arithmetic after widening, one rounding at the end
+        assert torch.equal(l0, l1)
+        assert torch.equal(g1, g0.to(torch.bfloat16))
+    else:            # float32 on the fused kernel, bfloat16 (rows not 8-byte aligned) on the three-kernel pipeline
+        assert torch.allclose(l0, l1, rtol=2e-6, atol=0)
+        assert ((g1.float() - g0).abs() <= 2.0 ** -8 * g0.abs() + 1e-6).all()
 
 
 @pytest.mark.parametrize("kind", ["classic", "simplified"])

@@ -798,8 +798,11 @@ static hipError_t launch5(const Problem &p, const Layout &L, float *a, float *b,
   if (plain)
     hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, 0>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
                        d_loss, grad, stamp);
-  else if (p.xdtype == 0)
+  else if (p.xdtype == 0 && ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0)
     hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, 1>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
+                       d_loss, grad, stamp);
+  else if (p.xdtype == 0)  // vocabulary or strides not a multiple of 4 elements: element-wise row accesses
+    hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, 3>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
                        d_loss, grad, stamp);
   else
     hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, 2>), grid, block, 0, st, p, L, a, b, lp, stats, loss,

@@ -147,7 +147,8 @@ struct Emis {
 //   A -> rows[t] : slot i = (state_c(l=i) [, open(l=i+1)]), tail.x = state_c(l=UP)       (read by B)
 //   B -> rows[t] : slot i = (state_c(l=i+1) [, open(l=i+1)]), tail.x = state_c(l=0)      (read by A)
 // XT: format of logits and gradient in HBM: 0 = contiguous float32 (frame stride V folded into the addressing),
-// 1 = float32 with run-time frame strides, 2 = bfloat16 with run-time frame strides.  Arithmetic is float32 either way.
+// 1 = float32 with run-time frame strides, 2 = bfloat16 with run-time frame strides, 3 = float32, any vocabulary size
+// and stride (rows not 16-byte aligned: element-wise loads and stores).  Arithmetic is float32 either way.
 template <int KIND, int NL, int VPL, int DIR, bool LOGITS, int XT = 0>
 struct Side {
   static constexpr int V = 256 * VPL;
@@ -194,6 +195,17 @@ struct Side {
         xr[q] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);  // tokens beyond the vocabulary: log 0
         if (lane * 4 + 256 * q < Vr) xr[q] = *reinterpret_cast<const float4 *>(row + 256 * q);
       }
+    } else if constexpr (XT == 3) {
+      const float *row = xbase + (long)t * xst + lane * 4;
+#pragma unroll
+      for (int q = 0; q < VPL; ++q) {
+        const int k = lane * 4 + 256 * q;
+        xr[q] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (k < Vr) xr[q].x = row[256 * q];
+        if (k + 1 < Vr) xr[q].y = row[256 * q + 1];
+        if (k + 2 < Vr) xr[q].z = row[256 * q + 2];
+        if (k + 3 < Vr) xr[q].w = row[256 * q + 3];
+      }
     } else {  // 4 bfloat16 = 8 bytes per lane; widening is a shift / mask
       const unsigned short *row = reinterpret_cast<const unsigned short *>(xbase) + (long)t * xst + lane * 4;
 #pragma unroll
@@ -211,6 +223,13 @@ struct Side {
       *reinterpret_cast<float4 *>(gbase + (long)t * V + lane * 4 + 256 * q) = r;
     } else if constexpr (XT == 1) {
       if (lane * 4 + 256 * q < Vr) *reinterpret_cast<float4 *>(gbase + (long)t * gst + lane * 4 + 256 * q) = r;
+    } else if constexpr (XT == 3) {
+      float *row = gbase + (long)t * gst + lane * 4 + 256 * q;
+      const int k = lane * 4 + 256 * q;
+      if (k < Vr) row[0] = r.x;
+      if (k + 1 < Vr) row[1] = r.y;
+      if (k + 2 < Vr) row[2] = r.z;
+      if (k + 3 < Vr) row[3] = r.w;
     } else {
       unsigned short *row = reinterpret_cast<unsigned short *>(gbase) + (long)t * gst + lane * 4 + 256 * q;
       uint2 w;
