@@ -72,12 +72,12 @@ def main():
         def gradient():
             x = logits.detach().requires_grad_(True)
             loss = fn(labels, x, ll, tl, 0)
-            return torch.autograd.grad(loss[torch.isfinite(loss)].sum(), x)[0]
+            return torch.autograd.grad(torch.where(torch.isfinite(loss), loss, 0.0).sum(), x)[0]
 
         def second():
             x = logits.detach().requires_grad_(True)
             loss = fn(labels, x, ll, tl, 0)
-            (g,) = torch.autograd.grad(loss[torch.isfinite(loss)].sum(), x, create_graph=True)
+            (g,) = torch.autograd.grad(torch.where(torch.isfinite(loss), loss, 0.0).sum(), x, create_graph=True)
             return torch.autograd.grad((g * v).sum(), x)[0]
 
         rows[name] = {"forward_ms": timeit(forward, a.steps, a.warmup), "gradient_ms": timeit(gradient, a.steps, a.warmup)}

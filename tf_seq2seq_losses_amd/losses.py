@@ -80,6 +80,12 @@ class _HessianContraction(torch.autograd.Function):
         raise NotImplementedError("Third order derivative over the ctc loss function is not implemented.")
 
 
+# Below this many logits the forward pass also produces the (unit) gradient and backward rescales it -- one launch instead
+# of two, which is what matters when launches dominate; above it the forward pass computes the loss only and backward runs
+# the kernel again with d_loss applied inside it -- no [B,T,V] tensor kept alive in between and no extra pass over it.
+_EAGER_GRADIENT_MAX_ELEMENTS = 1 << 22
+
+
 class _CtcGradient(torch.autograd.Function):
     """gradient_fn (base_loss.py:157-175) composed with forward_fn.backprop (base_loss.py:150-153):
     returns d_loss[:,None,None] * gradient and differentiates to the Hessian contraction."""
@@ -87,36 +93,43 @@ class _CtcGradient(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, d_loss, kind, wrt, prep, grad_unit):
         ctx.kind, ctx.wrt, ctx.prep = kind, wrt, prep
-        ctx.save_for_backward(x, d_loss, grad_unit)
-        return (d_loss.reshape(-1, 1, 1) * grad_unit).to(grad_unit.dtype)
+        ctx.save_for_backward(x, d_loss)
+        if grad_unit is not None:
+            return (d_loss.reshape(-1, 1, 1) * grad_unit).to(grad_unit.dtype)
+        return ops.loss_grad(kind, wrt, prep, True, d_loss=d_loss)[1]  # weighting inside the kernel
 
     @staticmethod
     def backward(ctx, dd):
-        x, d_loss, grad_unit = ctx.saved_tensors
+        x, d_loss = ctx.saved_tensors
         gx = gd = None
         if ctx.needs_input_grad[0]:
             gx = _HessianContraction.apply(x, dd * d_loss.reshape(-1, 1, 1), ctx.kind, ctx.wrt, ctx.prep)
         if ctx.needs_input_grad[1]:
+            grad_unit = ops.loss_grad(ctx.kind, ctx.wrt, ctx.prep, True)[1]
             gd = (dd.float() * grad_unit.float()).sum(dim=(1, 2)).to(d_loss.dtype)
         return gx, gd, None, None, None, None
 
 
 class _CtcLoss(torch.autograd.Function):
-    """forward_fn (base_loss.py:140-155).  Loss and the unit gradient come out of ONE kernel pipeline
-    (ctc_amd_loss_grad); the gradient is kept for backward."""
+    """forward_fn (base_loss.py:140-155).  Small problems: loss and unit gradient from ONE kernel pipeline, the gradient
+    kept for backward.  Large problems: the loss only (the fused kernel stops where its two chains meet); the gradient is
+    computed when -- and if -- backward asks for it, already weighted by d_loss."""
 
     @staticmethod
     def forward(ctx, x, kind, wrt, prep):
-        need = x.requires_grad
-        loss, grad = ops.loss_grad(kind, wrt, prep, want_grad=need)
+        eager = x.requires_grad and x.numel() <= _EAGER_GRADIENT_MAX_ELEMENTS
+        loss, grad = ops.loss_grad(kind, wrt, prep, want_grad=eager)
         ctx.kind, ctx.wrt, ctx.prep = kind, wrt, prep
-        if need:
+        if eager:
             ctx.save_for_backward(x, grad)
+        else:
+            ctx.save_for_backward(x)
         return loss
 
     @staticmethod
     def backward(ctx, d_loss):
-        x, grad_unit = ctx.saved_tensors
+        x = ctx.saved_tensors[0]
+        grad_unit = ctx.saved_tensors[1] if len(ctx.saved_tensors) > 1 else None
         return _CtcGradient.apply(x, d_loss, ctx.kind, ctx.wrt, ctx.prep, grad_unit), None, None, None
 
 
