@@ -23,6 +23,15 @@ namespace ctc {
 
 using namespace ctc::fused;
 
+// The Hessian is written once and never read here: non-temporal stores keep 21 GB of output out of the caches the
+// sweeps read their lattice, emission and gradient rows through.
+__device__ __forceinline__ void nt_store(float *p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void nt_store(float *p, float4 r) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f v = {r.x, r.y, r.z, r.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
+}
+
 template <int KIND, int NL>
 __global__ __launch_bounds__(256) void hess_slab_kernel(Problem p, Layout L, const float *__restrict__ emis,
                                                          const float *__restrict__ alpha, const float *__restrict__ beta,
@@ -55,9 +64,9 @@ __global__ __launch_bounds__(256) void hess_slab_kernel(Problem p, Layout L, con
     float *q = out + (long)t_from * V;
     const long n = (long)(t_to - t_from) * V;
     if (((n | (q - hess)) & 3) == 0) {
-      for (long k = 4l * lane; k < n; k += 256) *reinterpret_cast<float4 *>(q + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (long k = 4l * lane; k < n; k += 256) nt_store(q + k, make_float4(0.f, 0.f, 0.f, 0.f));
     } else {
-      for (long k = lane; k < n; k += 64) q[k] = 0.f;
+      for (long k = lane; k < n; k += 64) nt_store(q + k, 0.f);
     }
   };
   const bool valid = (t1 < len) && (lp != -INFINITY) && (ll <= p.U);
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(256) void hess_slab_kernel(Problem p, Layout L, con
     if (lane == 0) ubin[p.blank] = tofix(qb);
     __builtin_amdgcn_wave_barrier();
     for (int k2 = lane; k2 < V; k2 += 64) {  // base_loss.py:235-237 : -exp(.) + g (x) g
-      out[(long)t2 * V + k2] = g1 * grow[(long)t2 * V + k2] - (float)ubin[k2] * 9.31322574615478515625e-10f;
+      nt_store(out + (long)t2 * V + k2, g1 * grow[(long)t2 * V + k2] - (float)ubin[k2] * 9.31322574615478515625e-10f);
       ubin[k2] = 0u;
     }
     __builtin_amdgcn_wave_barrier();
@@ -365,9 +374,9 @@ __global__ __launch_bounds__(256, 6) void hess_pair_kernel(Problem p, Layout L, 
   const bool have_b = 2 * pair + 1 < V;
   auto fill_zero = [&](float *q, long n) {                // whole wavefront, wave-uniform arguments
     if (((n | (q - hess)) & 3) == 0) {
-      for (long k = 4l * lane; k < n; k += 256) *reinterpret_cast<float4 *>(q + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (long k = 4l * lane; k < n; k += 256) nt_store(q + k, make_float4(0.f, 0.f, 0.f, 0.f));
     } else {
-      for (long k = lane; k < n; k += 64) q[k] = 0.f;
+      for (long k = lane; k < n; k += 64) nt_store(q + k, 0.f);
     }
   };
   float *out_a = hess + (((long)b * T + t1) * V + k1a) * slab;
@@ -480,8 +489,8 @@ __global__ __launch_bounds__(256, 6) void hess_pair_kernel(Problem p, Layout L, 
   auto fill_step = [&]() {
     if (f_done) return;
     const int n = f_left < funit ? (int)f_left : funit;
-    if (vec4) { if (4 * lane < n) *reinterpret_cast<float4 *>(f_ptr + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f); }
-    else if (lane < n) f_ptr[lane] = 0.f;
+    if (vec4) { if (4 * lane < n) nt_store(f_ptr + 4 * lane, make_float4(0.f, 0.f, 0.f, 0.f)); }
+    else if (lane < n) nt_store(f_ptr + lane, 0.f);
     f_ptr += n;
     f_left -= n;
     if (f_left == 0) f_advance();
@@ -596,9 +605,9 @@ __global__ __launch_bounds__(256, 6) void hess_pair_kernel(Problem p, Layout L, 
       float *dst = out + (long)lo * V;
       const int n = (hi - lo + 1) * V;
       if (vec4) {
-        for (int k = 4 * hl; k < n; k += 4 * W) *reinterpret_cast<float4 *>(dst + k) = *reinterpret_cast<const float4 *>(src + k);
+        for (int k = 4 * hl; k < n; k += 4 * W) nt_store(dst + k, *reinterpret_cast<const float4 *>(src + k));
       } else {
-        for (int k = hl; k < n; k += W) dst[k] = src[k];
+        for (int k = hl; k < n; k += W) nt_store(dst + k, src[k]);
       }
     }
     __builtin_amdgcn_wave_barrier();
