@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void hvp_out_kernel(Problem p, Layout L, const
   const double lp = logp[b];
   int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
   if (t >= len || lp == -INFINITY || ll > p.U) {
-    for (int k = lane; k < V; k += 64) o[k] = 0.f;  // the Hessian vanishes there (base_loss.py:240-258)
+    for (int k = lane; k < V; k += 64) __builtin_nontemporal_store(0.f, o + k);  // the Hessian vanishes there (base_loss.py:240-258)
     return;
   }
   float *bin = lds + (long)w * V;
@@ -387,10 +387,10 @@ __global__ __launch_bounds__(256) void hvp_out_kernel(Problem p, Layout L, const
     const float sv = demis[row * (long)L.ERS + UP + 1];
     for (int k = lane; k < V; k += 64) {
       const float s = fexp2((x[k] - mx) * LOG2E - l2s);
-      o[k] = -bin[k] + s * (v[k] - sv);  // H_lp u + (diag(s) - s s^T) v
+      __builtin_nontemporal_store(-bin[k] + s * (v[k] - sv), o + k);  // H_lp u + (diag(s) - s s^T) v
     }
   } else {
-    for (int k = lane; k < V; k += 64) o[k] = -bin[k];
+    for (int k = lane; k < V; k += 64) __builtin_nontemporal_store(-bin[k], o + k);
   }
 }
 

@@ -394,13 +394,19 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
   float *g = grad + goff;                                                        // valid for float32 only
   unsigned short *gh = reinterpret_cast<unsigned short *>(grad) + goff;           // valid for bfloat16 only
   const bool gbf = p.gdtype != 0;
-  auto gput = [&](int k, float v) { if (gbf) gh[k] = f32_to_bf16(v); else g[k] = v; };
+  // outputs are written once and not read here: non-temporal stores
+  auto gput = [&](int k, float v) { if (gbf) __builtin_nontemporal_store(f32_to_bf16(v), gh + k); else __builtin_nontemporal_store(v, g + k); };
+  auto gput4 = [&](int k, float4 r) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f v = {r.x, r.y, r.z, r.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(g + k));
+  };
   const bool gvec = !gbf && ((V | goff) & 3) == 0;
   const int len = clampi(p.logit_length[b], 0, p.T);
   const double lp = logp[b];
   if (t >= len || lp == -INFINITY) {
     // padded frames and infeasible samples: exactly zero (base_loss.py:283-298)
-    if (gvec) for (int k = lane * 4; k < V; k += 256) *reinterpret_cast<float4 *>(g + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gvec) for (int k = lane * 4; k < V; k += 256) gput4(k, make_float4(0.f, 0.f, 0.f, 0.f));
     else for (int k = lane; k < V; k += 64) gput(k, 0.f);
     return;
   }
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
         r.y = dl * (fexp2((v.y - mx) * LOG2E - l2s) - q.y);
         r.z = dl * (fexp2((v.z - mx) * LOG2E - l2s) - q.z);
         r.w = dl * (fexp2((v.w - mx) * LOG2E - l2s) - q.w);
-        *reinterpret_cast<float4 *>(g + k) = r;
+        gput4(k, r);
       }
     } else {
       for (int k = lane; k < V; k += 64) {
