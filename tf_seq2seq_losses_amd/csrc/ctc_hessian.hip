@@ -616,9 +616,9 @@ __global__ __launch_bounds__(256, 6) void hess_pair_kernel(Problem p, Layout L, 
   auto emit_row = [&](int t2, float s1, float s2, float s0, float gq0, float gq1) {
     float qb = (first ? fexp2(s0) : 0.f) + fexp2(s1);
     atomicAdd(reinterpret_cast<unsigned *>(abin), tofix(fexp2(s2)));
-    qb = half_sum(qb);
+    asm(CTC_HALF_REDUCE_ASM("v_add_f32_dpp") : "+v"(qb));  // lanes 31 / 63 now hold their half's sum ...
     HST(5);
-    if (first) ubin[p.blank] = tofix(qb);
+    if (last) ubin[p.blank] = tofix(qb);                    // ... and write it: no broadcast needed
     __builtin_amdgcn_wave_barrier();
     float *srow = stage + (t2 & (SR - 1)) * V + hl;
     // base_loss.py:235-237 : -exp(.) + g (x) g ; the first two chunks use the prefetched gradient values
