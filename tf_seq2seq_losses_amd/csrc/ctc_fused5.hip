@@ -4,14 +4,15 @@
 //   wave 0 / 1 : main chain A / B -- the lattice recursion only (alpha forward from frame 0, beta backward from frame
 //                len-1, meeting in the middle like ctc_fused.hip / ctc_fused4.hip).  Phase 1 leaves ONE checkpoint row per
 //                block in HBM (1/BLK of the rows ctc_fused4.hip spills).  Phase 2 reads everything from LDS.
-//   wave 2 / 3 : recompute chain for A / for B -- phase 2 only.  For the block its main chain will process next it restarts
+//   wave 2 / 3 : recompute chain for A / for B.  Phase 2: for the block its main chain will process next it restarts
 //                the OTHER side's recursion from that side's checkpoint and regenerates the BLK lattice rows into LDS
 //                (R rows): beta rows for A's blocks, alpha rows for B's.  It reuses the emissions the helpers already
-//                staged for that block (emissions do not depend on the direction).
+//                staged for that block (emissions do not depend on the direction).  Phase 1 (nothing to recompute yet):
+//                it works part of its side's E stage (estage1).
 //   waves 4..  : NH helpers per side -- logits rows from HBM (prefetched a block ahead in registers), log-softmax
 //                statistics by DPP reductions, emission gather through an LDS copy of the row (E stage); posterior scatter
-//                with ds_add_f32 into an LDS token row and the softmax - posterior store (G stage).  The logits rows of a
-//                block stay in the helper's registers from its E stage to its G stage.
+//                with fixed-point ds_add_u32 into an LDS token row and the softmax - posterior store, non-temporal (G
+//                stage).  The logits rows of a block stay in the helper's registers from its E stage to its G stage.
 //
 //   Pipeline per side, iteration `it`:  E(block it) -> recompute(block it-1) -> main(block it-2) -> G(block it-3);
 //   E and R/S rows are triple-buffered in LDS; all wavefronts meet at ONE raw s_barrier per iteration and derive the same
@@ -22,7 +23,9 @@
 //   8 bytes of softmax statistics per frame: ~1.55x the algorithmic 2*T*V*4 bytes (ctc_fused4.hip: 2.5x, v1: 4.4x).
 //
 // References: classic_ctc_loss.py:310-462,565-669, simplified_ctc_loss.py:291-438,456-534, base_loss.py:262-298,328-344,
-// 420-468, tools.py:27-40.  Eligibility: V = 256, U <= 128 (LDS budget); otherwise ctc_fused.hip / the v1 pipeline run.
+// 420-468, tools.py:27-40.  Eligibility: V <= 256, U <= 128 (LDS budget); otherwise ctc_fused.hip / the v1 pipeline run.
+// Instantiated per input/output format XT (Side in ctc_fused_common.h): contiguous float32, strided float32, bfloat16,
+// and float32 rows that are not 16-byte aligned.  With grad == NULL every role returns at the meeting point (loss only).
 #include "ctc_fused_common.h"
 
 #ifndef CTC_FUSED_KIND

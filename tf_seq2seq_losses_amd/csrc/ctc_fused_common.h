@@ -1,5 +1,6 @@
 // Building blocks shared by the fused loss+gradient kernels (ctc_fused.hip: two self-contained wavefronts per
-// utterance; ctc_fused4.hip: chain + helper wavefronts).  See those files for the algorithms.
+// utterance; ctc_fused4.hip: chain + helper wavefronts; ctc_fused5.hip: chains + recompute chains + helpers) and by the
+// Hessian sweeps (ctc_hessian.hip).  See those files for the algorithms.
 #pragma once
 #include <type_traits>
 
