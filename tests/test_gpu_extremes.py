@@ -1,0 +1,67 @@
+"""Corner shapes of ctc_amd_loss_grad: one-token vocabularies, single frames, long utterances, many utterances."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as C
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(kind, logits, labels, ll, tl):
+    from tf_seq2seq_losses_amd import ops, _lib
+    dev = torch.device("cuda:0")
+    p = ops.Prepared(torch.from_numpy(labels).to(dev), torch.from_numpy(logits).to(dev), torch.from_numpy(ll).to(dev),
+                     torch.from_numpy(tl).to(dev), 0, U=labels.shape[1])
+    loss, grad = ops.loss_grad(ops.KINDS[kind], _lib.WRT_LOGITS, p, True)
+    return loss.cpu().numpy(), grad.cpu().numpy()
+
+
+def _check(kind, logits, labels, ll, tl, tol_g=1e-4):
+    lossn, gradn = _run(kind, logits, labels, ll, tl)
+    rl, rg = C.loss_grad(kind, labels, logits, ll, tl, 0)
+    fin = np.isfinite(rl)
+    assert np.array_equal(np.isfinite(lossn), fin)
+    if fin.any():
+        assert (np.abs(lossn[fin] - rl[fin]) / np.maximum(1.0, np.abs(rl[fin]))).max() < 1e-4
+    assert np.isfinite(gradn).all()
+    assert np.abs(gradn - rg).max() < tol_g
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_blank_only_vocabulary(kind):
+    rng = np.random.default_rng(0)
+    logits = rng.standard_normal((3, 7, 1)).astype(np.float32)
+    labels = np.zeros((3, 1), np.int32)
+    _check(kind, logits, labels, np.zeros(3, np.int32), np.array([7, 0, 3], np.int32))  # loss = 0: only the blank path
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+@pytest.mark.parametrize("V", [2, 3])
+def test_tiny_vocabulary_single_frame(kind, V):
+    rng = np.random.default_rng(1)
+    logits = rng.standard_normal((4, 1, V)).astype(np.float32)
+    labels = np.ones((4, 2), np.int32)
+    _check(kind, logits, labels, np.array([0, 1, 2, 1], np.int32), np.array([1, 1, 1, 0], np.int32))
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_long_utterances(kind):
+    """T = 5000 (five times the north-star length): 209 blocks per side in the fused kernel.  The float32 lattice carries
+    ~4e-6 of rounding per step on renormalised values of magnitude ~100 bits, which accumulates roughly linearly with T:
+    2.6e-4 at T = 1000 (tests/test_gpu_large.py), 1.3e-3 measured here -- bound 3e-3; the loss (offsets in double) keeps
+    its 1e-4 relative bound."""
+    rng = np.random.default_rng(2)
+    B, T, V, U = 3, 5000, 256, 128
+    logits = rng.standard_normal((B, T, V)).astype(np.float32)
+    labels = rng.integers(1, V, (B, U)).astype(np.int32)
+    _check(kind, logits, labels, np.array([128, 77, 128], np.int32), np.array([5000, 4321, 2500], np.int32), tol_g=3e-3)
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_many_short_utterances(kind):
+    rng = np.random.default_rng(3)
+    B, T, V, U = 3000, 9, 8, 3
+    logits = rng.standard_normal((B, T, V)).astype(np.float32)
+    labels = rng.integers(1, V, (B, U)).astype(np.int32)
+    _check(kind, logits, labels, rng.integers(0, U + 1, B).astype(np.int32), rng.integers(0, T + 1, B).astype(np.int32))
