@@ -652,24 +652,29 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         S.zero_rows(len, T);  // padded frames (base_loss.py:291-296)
       }
     }
-    float4 xb[FPH][1];
-    float4 xg1[FPH][1], xg2[FPH][1], xg3[FPH][1];  // logits rows of the three previous blocks (G stage)
-    static_for<0, FPH>([&](auto Q) {
-      constexpr int q = decltype(Q)::value;
-      xg1[q][0] = make_float4(0.f, 0.f, 0.f, 0.f); xg2[q][0] = xg1[q][0]; xg3[q][0] = xg1[q][0];
+    // The logits rows of a block are loaded one block ahead of its E stage and used again by its G stage three blocks
+    // later: five blocks are alive at a time.  They sit in a ring of five register sets addressed by (block mod 5) at
+    // COMPILE time -- the loop is unrolled by five -- instead of being moved from set to set every block (48 v_mov per
+    // block, 7 % of the phase-2 instructions of a helper).  The statistics of a block travel the same way.
+    constexpr int RING = 5;
+    float4 X[RING][FPH][1];
+    float2 SG[RING];
+    static_for<0, RING>([&](auto R) {
+      SG[decltype(R)::value] = make_float2(0.f, 0.f);
+      static_for<0, FPH>([&](auto Q) { X[decltype(R)::value][decltype(Q)::value][0] = make_float4(0.f, 0.f, 0.f, 0.f); });
     });
     float2 st_cur = make_float2(0.f, 0.f), st_next = make_float2(0.f, 0.f);
-    float2 sg1 = st_cur, sg2 = st_cur, sg3 = st_cur;  // the statistics travel with the rows
     if (nb > 0) {
-      static_for<0, FPH>([&](auto Q) { S.load_x(xb[decltype(Q)::value], fr(2, 0, h + NH * decltype(Q)::value)); });
+      static_for<0, FPH>([&](auto Q) { S.load_x(X[0][decltype(Q)::value], fr(2, 0, h + NH * decltype(Q)::value)); });
       st_cur = stats[fr(2, 0, lane)];
     }
-    for (int it = 0; it <= geo.NB + 2; ++it) {
+    auto body = [&](auto R, int it) __attribute__((always_inline)) {
+      constexpr int r = decltype(R)::value;         // = it mod 5
+      constexpr int rn = (r + 1) % RING;            // block it+1 (being loaded)
+      constexpr int rg = (r + 2) % RING;            // block it-3 (G stage)
       // ---- E stage (block it) ----
       const int j = it;
-      float4 xe[FPH][1];
-      static_for<0, FPH>([&](auto Q) { xe[decltype(Q)::value][0] = xg1[decltype(Q)::value][0]; });
-      float2 se = st_cur;
+      SG[r] = st_cur;
 #ifdef CTC_DBG_NO_E2
       if (false) {
 #else
@@ -679,14 +684,13 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         const int nv = geo.nvof(g);
         float(*E)[LD::ES] = lds.E[DIR][j % 3];
         st_next = stats[fr(2, j + 1, lane)];
-        if (nv == BLK) {
+        if (__builtin_expect(nv == BLK, 1)) {
           static_for<0, FPH>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             const int d = h + NH * q;
             Emis<NL> e;
-            S.gather(xb[q], 0, readlane_f(st_cur.x, d), readlane_f(st_cur.y, d), e);
+            S.gather(X[r][q], 0, readlane_f(st_cur.x, d), readlane_f(st_cur.y, d), e);
             write_E(E[d], e);
-            xe[q][0] = make_float4(xb[q][0].x, xb[q][0].y, xb[q][0].z, xb[q][0].w);
           });
         } else {
           for (int d = h; d < nv; d += NH) {
@@ -698,7 +702,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
             write_E(E[d], e);
           }
         }
-        static_for<0, FPH>([&](auto Q) { S.load_x(xb[decltype(Q)::value], fr(2, j + 1, h + NH * decltype(Q)::value)); });
+        static_for<0, FPH>([&](auto Q) { S.load_x(X[rn][decltype(Q)::value], fr(2, j + 1, h + NH * decltype(Q)::value)); });
         st_cur = st_next;
       }
       // ---- G stage (block it-3): posterior scatter + gradient rows ----
@@ -730,11 +734,11 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
           e.mx = mx; e.l2s = l2s;
           S.grad_row(geo.frame(DIR, g, d), s1, s2, s0, xr, e);
         };
-        if (nv == BLK) {
+        if (__builtin_expect(nv == BLK, 1)) {
           static_for<0, FPH>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             const int d = h + NH * q;
-            g_frame(d, xg3[q], readlane_f(sg3.x, d), readlane_f(sg3.y, d));
+            g_frame(d, X[rg][q], readlane_f(SG[rg].x, d), readlane_f(SG[rg].y, d));
           });
         } else {
           for (int d = h; d < nv; d += NH) {
@@ -745,14 +749,14 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
           }
         }
       }
-      static_for<0, FPH>([&](auto Q) {  // rotate the kept rows: it-2 -> it-3, it-1 -> it-2, it -> it-1
-        constexpr int q = decltype(Q)::value;
-        xg3[q][0] = xg2[q][0]; xg2[q][0] = xg1[q][0]; xg1[q][0] = xe[q][0];
-      });
-      sg3 = sg2; sg2 = sg1; sg1 = se;
       STAMP(st.mid());
       block_barrier();
       STAMP(st.end());
+    };
+    for (int it0 = 0; it0 <= geo.NB + 2; it0 += RING) {
+      static_for<0, RING>([&](auto R) {
+        if (it0 + decltype(R)::value <= geo.NB + 2) body(R, it0 + decltype(R)::value);
+      });
     }
   }
   STAMP(st.dump(reinterpret_cast<unsigned long long *>(stamp_ws) + ((long)b * LD::NW + 4 + DIR * NH + h) * 4, lane));
