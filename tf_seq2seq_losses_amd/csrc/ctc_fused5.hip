@@ -727,12 +727,13 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
             s1[0] = v.x; s2[0] = v.y; s1[1] = v.z; s2[1] = v.w;
           }
           const float2 t0 = *reinterpret_cast<const float2 *>(row + 2 * LD::UP);  // (s0, posterior scale of the block)
+          const float sc30 = t0.y + 30.0f;  // block scale + the 2^30 fixed-point unit of the token row (grad_row30)
 #pragma unroll
-          for (int jj = 0; jj < NL; ++jj) { s1[jj] += t0.y; s2[jj] += t0.y; }
-          const float s0 = t0.x + t0.y;
+          for (int jj = 0; jj < NL; ++jj) { s1[jj] += sc30; s2[jj] += sc30; }
+          const float s0 = t0.x + sc30;
           Emis<NL> e;
           e.mx = mx; e.l2s = l2s;
-          S.grad_row(geo.frame(DIR, g, d), s1, s2, s0, xr, e);
+          S.grad_row30(geo.frame(DIR, g, d), s1, s2, s0, xr, e);
         };
         if (__builtin_expect(nv == BLK, 1)) {
           static_for<0, FPH>([&](auto Q) {
