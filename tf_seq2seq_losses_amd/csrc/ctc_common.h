@@ -66,6 +66,14 @@ struct Problem {
 
 // bfloat16 <-> float32 (round to nearest even on the way back)
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+// two at once: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, round to nearest even) -- lo in bits 0..15
+__device__ __forceinline__ unsigned f32x2_to_bf16x2(float lo, float hi) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  f2 v = {lo, hi};
+  b2 w = __builtin_convertvector(v, b2);
+  return __builtin_bit_cast(unsigned, w);
+}
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   const unsigned u = __float_as_uint(f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN

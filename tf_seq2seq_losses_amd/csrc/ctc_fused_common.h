@@ -242,8 +242,8 @@ struct Side {
       unsigned short *row = reinterpret_cast<unsigned short *>(gbase) + (long)t * gst + lane * 4 + 256 * q;
       typedef unsigned v2u __attribute__((ext_vector_type(2)));
       v2u w;
-      w.x = (unsigned)f32_to_bf16(r.x) | ((unsigned)f32_to_bf16(r.y) << 16);
-      w.y = (unsigned)f32_to_bf16(r.z) | ((unsigned)f32_to_bf16(r.w) << 16);
+      w.x = f32x2_to_bf16x2(r.x, r.y);
+      w.y = f32x2_to_bf16x2(r.z, r.w);
       if (lane * 4 + 256 * q < Vr) __builtin_nontemporal_store(w, reinterpret_cast<v2u *>(row));
     }
   }
