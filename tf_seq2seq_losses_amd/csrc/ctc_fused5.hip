@@ -102,15 +102,51 @@ struct Geo {
   __device__ __forceinline__ int frame(int side, int g, int d) const { return side == 0 ? BLK * g + d : BLK * g + nvof(g) - 1 - d; }
 };
 
+// NL consecutive floats (or NL consecutive (a, b) pairs) of this lane in an LDS / HBM row, NL = 1, 2, 4: widest accesses
+template <int NL>
+__device__ __forceinline__ void ld_slots(const float *p, float (&v)[NL]) {
+  if constexpr (NL == 1) v[0] = p[0];
+  else if constexpr (NL == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y; }
+  else {
+#pragma unroll
+    for (int q = 0; q < NL / 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4 *>(p + 4 * q);
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+  }
+}
+template <int NL>
+__device__ __forceinline__ void st_slots(float *p, const float (&v)[NL]) {
+  if constexpr (NL == 1) p[0] = v[0];
+  else if constexpr (NL == 2) *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+  else {
+#pragma unroll
+    for (int q = 0; q < NL / 4; ++q) *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  }
+}
+template <int NL>
+__device__ __forceinline__ void ld_pairs(const float *p, float (&a)[NL], float (&b)[NL]) {
+  if constexpr (NL == 1) { const float2 t = *reinterpret_cast<const float2 *>(p); a[0] = t.x; b[0] = t.y; }
+  else {
+#pragma unroll
+    for (int q = 0; q < NL / 2; ++q) {
+      const float4 t = *reinterpret_cast<const float4 *>(p + 4 * q);
+      a[2 * q] = t.x; b[2 * q] = t.y; a[2 * q + 1] = t.z; b[2 * q + 1] = t.w;
+    }
+  }
+}
+template <int NL>
+__device__ __forceinline__ void st_pairs(float *p, const float (&a)[NL], const float (&b)[NL]) {
+  if constexpr (NL == 1) *reinterpret_cast<float2 *>(p) = make_float2(a[0], b[0]);
+  else {
+#pragma unroll
+    for (int q = 0; q < NL / 2; ++q) *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(a[2 * q], b[2 * q], a[2 * q + 1], b[2 * q + 1]);
+  }
+}
+
 template <int NL, class LDt>
 __device__ __forceinline__ void read_E(const float *row, int lane, Emis<NL> &e) {
-  const float *q = row + lane * NL;
-  if constexpr (NL == 1) {
-    e.y[0] = q[0];
-  } else {
-    float2 v = *reinterpret_cast<const float2 *>(q);
-    e.y[0] = v.x; e.y[1] = v.y;
-  }
+  ld_slots<NL>(row + lane * NL, e.y);
   float4 tl = *reinterpret_cast<const float4 *>(row + LDt::UP);  // same address in every lane: LDS broadcast
   e.bl = tl.x; e.mx = tl.y; e.l2s = tl.z;
 }
@@ -119,38 +155,21 @@ __device__ __forceinline__ void read_E(const float *row, int lane, Emis<NL> &e) 
 template <int KIND, int NL, class LDt>
 __device__ __forceinline__ void read_R(const float *row, int lane, SRow<KIND, NL> &r) {
   if constexpr (KIND == 0) {
-    const float *q = row + 2 * lane * NL;
-    if constexpr (NL == 1) {
-      float2 v = *reinterpret_cast<const float2 *>(q);
-      r.a[0] = v.x; r.b[0] = v.y;
-    } else {
-      float4 v = *reinterpret_cast<const float4 *>(q);
-      r.a[0] = v.x; r.b[0] = v.y; r.a[1] = v.z; r.b[1] = v.w;
-    }
+    ld_pairs<NL>(row + 2 * lane * NL, r.a, r.b);
     r.tail = *reinterpret_cast<const float4 *>(row + 2 * LDt::UP);
   } else {
-    const float *q = row + lane * NL;
-    if constexpr (NL == 1) {
-      r.a[0] = q[0];
-    } else {
-      float2 v = *reinterpret_cast<const float2 *>(q);
-      r.a[0] = v.x; r.a[1] = v.y;
-    }
+    ld_slots<NL>(row + lane * NL, r.a);
     r.tail = *reinterpret_cast<const float4 *>(row + LDt::UP);
   }
 }
 template <int KIND, int NL, class LDt>
 __device__ __forceinline__ void write_R(float *row, float *dump, int lane, const float (&a)[NL], const float (&b)[NL], float4 tail) {
   if constexpr (KIND == 0) {
-    float *q = row + 2 * lane * NL;
-    if constexpr (NL == 1) *reinterpret_cast<float2 *>(q) = make_float2(a[0], b[0]);
-    else *reinterpret_cast<float4 *>(q) = make_float4(a[0], b[0], a[1], b[1]);
+    st_pairs<NL>(row + 2 * lane * NL, a, b);
     float *tq = (lane == 0) ? row + 2 * LDt::UP : dump + (lane & 15) * 4;
     *reinterpret_cast<float4 *>(tq) = tail;
   } else {
-    float *q = row + lane * NL;
-    if constexpr (NL == 1) q[0] = a[0];
-    else *reinterpret_cast<float2 *>(q) = make_float2(a[0], a[1]);
+    st_slots<NL>(row + lane * NL, a);
     float *tq = (lane == 0) ? row + LDt::UP : dump + (lane & 15) * 4;
     *reinterpret_cast<float4 *>(tq) = tail;
   }
@@ -225,13 +244,24 @@ __device__ __forceinline__ void init_labels(S_t &S, const Problem &p, int b, int
 #ifndef CTC_F5_Y
 #define CTC_F5_Y 3
 #endif
-template <int BLK>
+template <int BLK, int NH>
 struct P1Split {
-  static constexpr int X = CTC_F5_X, Y = CTC_F5_Y, R = BLK - 2 * X - 2 * Y;
+  // NH = 4 (12-frame blocks): X / X / Y / Y / R as above.  NH = 2 (6-frame blocks of the 4-positions-per-lane variant):
+  // the two helpers and the recompute wavefront take a third each.
+  static constexpr int X = NH == 4 ? CTC_F5_X : BLK / 3, Y = NH == 4 ? CTC_F5_Y : BLK / 3;
+  static constexpr int R = NH == 4 ? BLK - 2 * X - 2 * Y : BLK - X - Y;
+  static_assert(NH == 4 || NH == 2, "helpers per side");
   static_assert(X >= 0 && Y >= 0 && R >= 0 && X <= 6 && Y <= 6 && R <= 6, "phase-1 split: at most 6 frames per worker");
-  // worker: 0, 1 = helpers on the chain SIMDs, 2, 3 = helpers on the recompute SIMDs, 4 = recompute wavefront
-  static constexpr int first(int worker) { return worker == 0 ? 0 : worker == 1 ? X : worker == 2 ? 2 * X : worker == 3 ? 2 * X + Y : 2 * X + 2 * Y; }
-  static constexpr int count(int worker) { return worker < 2 ? X : worker < 4 ? Y : R; }
+  // worker: 0 .. NH-1 = helpers, NH = recompute wavefront
+  static constexpr int count(int worker) {
+    if (NH == 4) return worker < 2 ? X : worker < 4 ? Y : R;
+    return worker == 0 ? X : worker == 1 ? Y : R;
+  }
+  static constexpr int first(int worker) {
+    int f = 0;
+    for (int w = 0; w < worker; ++w) f += count(w);
+    return f;
+  }
 };
 
 template <int KIND, int NL, int NH, int BLK, int SIDE, int P0, int NQ, class S_t>
@@ -241,9 +271,7 @@ __device__ __forceinline__ void estage1(const S_t &S, Lds<KIND, NL, NH, BLK> &ld
   const int len = geo.len;
   const int nb = geo.nblocks(1, SIDE);
   auto write_E = [&](float *row, const Emis<NL> &e) __attribute__((always_inline)) {
-    float *q = row + lane * NL;
-    if constexpr (NL == 1) q[0] = e.y[0];
-    else *reinterpret_cast<float2 *>(q) = make_float2(e.y[0], e.y[1]);
+    st_slots<NL>(row + lane * NL, e.y);
     float *tq = (lane == 0) ? row + LD::UP : dump + (lane & 15) * 4;  // lanes >= 16 overlap in the sink: harmless
     *reinterpret_cast<float4 *>(tq) = make_float4(e.bl, e.mx, e.l2s, 0.f);
   };
@@ -427,9 +455,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
           float s1[NL], s2[NL], s0;
           S.post_step_sc(e, r, 0.f, s1, s2, s0);  // exponents WITHOUT the scale: the G stage adds it (off the chain)
           float *row = RR[d];  // S row in place
-          float *q = row + 2 * lane * NL;
-          if constexpr (NL == 1) *reinterpret_cast<float2 *>(q) = make_float2(s1[0], s2[0]);
-          else *reinterpret_cast<float4 *>(q) = make_float4(s1[0], s2[0], s1[1], s2[1]);
+          st_pairs<NL>(row + 2 * lane * NL, s1, s2);
           float *tq = (lane == 0) ? row + 2 * LD::UP : dump + lane;
           *reinterpret_cast<float2 *>((lane == 0) ? row + 2 * LD::UP : dump + (lane & 31) * 2) = make_float2(s0, sc);
           (void)tq;
@@ -482,7 +508,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
   STAMP(Stamps st; st.begin());
 
   {  // phase 1: nothing to recompute yet -- this wavefront works the E stage of its side (estage1)
-    using SP = P1Split<BLK>;
+    using SP = P1Split<BLK, NH>;
     S.xbase = XT != 2 ? p.logits + (long)b * p.xsb
                       : reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(p.logits) + (long)b * p.xsb);
     S.xst = p.xst;
@@ -490,7 +516,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
     S.xs = lds.xcopy_r[SIDE];
     if (lane == 0) S.xs[256] = -6.0e29f;  // pad slot of the gather copy: "log 0" for label positions beyond label_length
     float2 *stats = stats_ws + (long)b * T;
-    estage1<KIND, NL, NH, BLK, SIDE, SP::first(4), SP::count(4)>(S, lds, geo, stats, dump, lane, st);
+    estage1<KIND, NL, NH, BLK, SIDE, SP::first(NH), SP::count(NH)>(S, lds, geo, stats, dump, lane, st);
   }
   STAMP(st.phase1_done());
   __syncthreads();
@@ -604,9 +630,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
   STAMP(Stamps st; st.begin());
 
   auto write_E = [&](float *row, const Emis<NL> &e) __attribute__((always_inline)) {
-    float *q = row + lane * NL;
-    if constexpr (NL == 1) q[0] = e.y[0];
-    else *reinterpret_cast<float2 *>(q) = make_float2(e.y[0], e.y[1]);
+    st_slots<NL>(row + lane * NL, e.y);
     float *tq = (lane == 0) ? row + LD::UP : dump + (lane & 15) * 4;  // lanes >= 16 overlap in the sink: harmless
     *reinterpret_cast<float4 *>(tq) = make_float4(e.bl, e.mx, e.l2s, 0.f);
   };
@@ -625,13 +649,17 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
 
   // ================= phase 1: E stage with statistics (estage1 above) =================
   {
-    using SP = P1Split<BLK>;
-    static_assert(NH == 4, "phase-1 split is written for 4 helpers per side");
-    switch (h) {
-      case 0: estage1<KIND, NL, NH, BLK, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, dump, lane, st); break;
-      case 1: estage1<KIND, NL, NH, BLK, DIR, SP::first(1), SP::count(1)>(S, lds, geo, stats, dump, lane, st); break;
-      case 2: estage1<KIND, NL, NH, BLK, DIR, SP::first(2), SP::count(2)>(S, lds, geo, stats, dump, lane, st); break;
-      default: estage1<KIND, NL, NH, BLK, DIR, SP::first(3), SP::count(3)>(S, lds, geo, stats, dump, lane, st); break;
+    using SP = P1Split<BLK, NH>;
+    if constexpr (NH == 4) {
+      switch (h) {
+        case 0: estage1<KIND, NL, NH, BLK, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, dump, lane, st); break;
+        case 1: estage1<KIND, NL, NH, BLK, DIR, SP::first(1), SP::count(1)>(S, lds, geo, stats, dump, lane, st); break;
+        case 2: estage1<KIND, NL, NH, BLK, DIR, SP::first(2), SP::count(2)>(S, lds, geo, stats, dump, lane, st); break;
+        default: estage1<KIND, NL, NH, BLK, DIR, SP::first(3), SP::count(3)>(S, lds, geo, stats, dump, lane, st); break;
+      }
+    } else {
+      if (h == 0) estage1<KIND, NL, NH, BLK, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, dump, lane, st);
+      else estage1<KIND, NL, NH, BLK, DIR, SP::first(1), SP::count(1)>(S, lds, geo, stats, dump, lane, st);
     }
   }
 
@@ -718,14 +746,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         auto g_frame = [&](int d, const float4(&xr)[1], float mx, float l2s) __attribute__((always_inline)) {
           const float *row = SR[d];
           float s1[NL], s2[NL];
-          const float *q = row + 2 * lane * NL;
-          if constexpr (NL == 1) {
-            float2 v = *reinterpret_cast<const float2 *>(q);
-            s1[0] = v.x; s2[0] = v.y;
-          } else {
-            float4 v = *reinterpret_cast<const float4 *>(q);
-            s1[0] = v.x; s2[0] = v.y; s1[1] = v.z; s2[1] = v.w;
-          }
+          ld_pairs<NL>(row + 2 * lane * NL, s1, s2);
           const float2 t0 = *reinterpret_cast<const float2 *>(row + 2 * LD::UP);  // (s0, posterior scale of the block)
           const float sc30 = t0.y + 30.0f;  // block scale + the 2^30 fixed-point unit of the token row (grad_row30)
 #pragma unroll
@@ -797,10 +818,10 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused5_kernel(Problem p, La
 
 }  // namespace fused5
 
-template <int NL>
+template <int NL, int NH, int BLK>
 static hipError_t launch5(const Problem &p, const Layout &L, float *a, float *b, double *lp, float2 *stats, float *loss,
                           const float *d_loss, float *grad, void *stamp, hipStream_t st) {
-  constexpr int NH = 4, BLK = 12;
+  static_assert(sizeof(fused5::Lds<CTC_FUSED_KIND, NL, NH, BLK>) <= 160 * 1024, "LDS budget of one CU");
   const bool plain = p.xdtype == 0 && p.V == 256 && p.xst == 256 && p.gst == 256;  // frame stride folded into the addressing
   const dim3 grid(p.B), block(64 * (4 + 2 * NH));
   if (plain)
@@ -830,8 +851,10 @@ hipError_t run_fused5_simplified
   float2 *stats = reinterpret_cast<float2 *>(ws + L.off_emis);  // the emission region of the v1 pipeline is free here
   void *stamp = ws + L.off_dummy;  // diagnostic builds (-DCTC_FUSED_STAMPS) write per-wavefront cycle counts here
   switch (L.NL) {
-    case 1: return launch5<1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
-    case 2: return launch5<2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
+    case 1: return launch5<1, 4, 12>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
+    case 2: return launch5<2, 4, 12>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
+    // 129 .. 256 label positions: four per lane; rows are twice as long, so 6-frame blocks and two helpers per side
+    case 4: return launch5<4, 2, 6>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -9,7 +9,7 @@ import torch
 from . import _lib
 
 KINDS = {"classic": _lib.CLASSIC, "simplified": _lib.SIMPLIFIED}
-FUSED_MAX_U = 128  # label positions the fused loss+gradient kernels hold in registers (two per lane)
+FUSED_MAX_U = 128  # label positions the fastest instantiation of the fused kernel holds (two per lane; 256 with four)
 
 
 def _require_gpu(t: torch.Tensor) -> None:
