@@ -238,13 +238,14 @@ __device__ __forceinline__ void init_labels(S_t &S, const Problem &p, int b, int
 // cycles per block, SIMD 2/3 nothing else in this phase).  The worker also records the statistics of its frames for the
 // other side's pass over them in phase 2.  One barrier per block, like every other role.
 // ------------------------------------------------------------------------------------------------
+// (measured: 1/3/4 for two label positions per lane, 2/3/2 for one -- the chain is half as long there)
 #ifndef CTC_F5_X
-#define CTC_F5_X 1
+#define CTC_F5_X (NL == 1 ? 2 : 1)
 #endif
 #ifndef CTC_F5_Y
 #define CTC_F5_Y 3
 #endif
-template <int BLK, int NH>
+template <int BLK, int NH, int NL>
 struct P1Split {
   // NH = 4 (12-frame blocks): X / X / Y / Y / R as above.  NH = 2 (6-frame blocks of the 4-positions-per-lane variant):
   // the two helpers and the recompute wavefront take a third each.
@@ -508,7 +509,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
   STAMP(Stamps st; st.begin());
 
   {  // phase 1: nothing to recompute yet -- this wavefront works the E stage of its side (estage1)
-    using SP = P1Split<BLK, NH>;
+    using SP = P1Split<BLK, NH, NL>;
     S.xbase = XT != 2 ? p.logits + (long)b * p.xsb
                       : reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(p.logits) + (long)b * p.xsb);
     S.xst = p.xst;
@@ -649,7 +650,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
 
   // ================= phase 1: E stage with statistics (estage1 above) =================
   {
-    using SP = P1Split<BLK, NH>;
+    using SP = P1Split<BLK, NH, NL>;
     if constexpr (NH == 4) {
       switch (h) {
         case 0: estage1<KIND, NL, NH, BLK, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, dump, lane, st); break;
