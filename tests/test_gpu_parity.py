@@ -200,7 +200,7 @@ def test_autograd_first_and_second_order(kind):
     ref = O.ctc_loss(kind, inp["labels"], inp["logits"], inp["label_length"], inp["logit_length"], 0)
     gref = O.logits_gradient(ref, inp["logits"], d_loss=w.cpu().numpy())
     assert np.abs(g.detach().cpu().numpy() - gref).max() < TOL
-    v = torch.randn_like(g)
+    v = torch.randn(g.shape, device=g.device, generator=torch.Generator(device=g.device).manual_seed(0))
     (hv,) = torch.autograd.grad((g * v).sum(), x, create_graph=True)
     href = np.einsum("btkuj,buj->btk", O.logits_hessian(ref, inp["logits"]), v.cpu().numpy()) * w.cpu().numpy()[:, None, None]
     assert np.abs(hv.detach().cpu().numpy() - href).max() < TOL
