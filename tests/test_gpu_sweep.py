@@ -14,7 +14,7 @@ CASES = []
 _rng = np.random.default_rng(2024)
 for T in (1, 2, 11, 12, 13, 23, 24, 25, 35, 36, 37, 47, 48, 49, 97, 240):
     U = int(_rng.choice([0, 1, 5, 63, 64, 65, 127, 128]))
-    V = int(_rng.choice([4, 8, 29, 60, 79, 252, 255, 256]))
+    V = int(_rng.choice([4, 8, 29, 60, 79, 252, 255, 256, 300, 512]))
     CASES.append((T, U, V, int(_rng.integers(1, 6))))
 for U in (0, 1, 2, 63, 64, 65, 127, 128, 129, 200):
     CASES.append((int(_rng.integers(U + 1, 2 * U + 40)), U, int(_rng.choice([12, 31, 256])), 4))

@@ -14,7 +14,7 @@ hipError_t run_fused_classic(const Problem &p, const Layout &L, char *ws, float 
 hipError_t run_fused_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 hipError_t run_fused5_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 hipError_t run_fused5_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
-// shapes the checkpoint + recompute kernel (ctc_fused5.hip) is instantiated for: logits input, V <= 256 (smaller
+// shapes the checkpoint + recompute kernel (ctc_fused5.hip) is instantiated for: logits input, V <= 512 (smaller
 // vocabularies run with the lanes beyond V masked; V or strides not a multiple of 4: element-wise row accesses), U <= 256
 inline bool plain_format(const Problem &p) {  // contiguous float32 [B,T,V] logits and gradient
   return p.xdtype == 0 && p.gdtype == 0 && p.xst == p.V && p.gst == p.V && p.xsb == (long)p.T * p.V && p.gsb == (long)p.T * p.V;
@@ -22,7 +22,7 @@ inline bool plain_format(const Problem &p) {  // contiguous float32 [B,T,V] logi
 inline bool fused5_eligible(const Problem &p, const Layout &L) {
   // producer formats: both tensors float32 or both bfloat16, strides keeping the 16-byte (8-byte) row accesses aligned
   // (bfloat16 needs 8-byte aligned rows: V and the strides multiples of 4; float32 takes any V <= 256 and any stride)
-  return p.wrt == 0 && p.V <= 256 && L.NL <= 4 && p.B > 0 && p.T > 0 && p.xdtype == p.gdtype &&
+  return p.wrt == 0 && p.V <= 512 && L.NL <= 4 && p.B > 0 && p.T > 0 && p.xdtype == p.gdtype &&
          (p.xdtype == 0 || ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0);
 }
 inline hipError_t run_fused5(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {

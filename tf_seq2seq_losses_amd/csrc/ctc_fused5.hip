@@ -64,9 +64,9 @@ struct Stamps {  // normal builds: nothing
 #endif
 #define STAMP(x) x
 
-template <int KIND, int NL, int NH, int BLK>
+template <int KIND, int NL, int NH, int BLK, int VPL>
 struct Lds {
-  static constexpr int V = 256, UP = 64 * NL;
+  static constexpr int V = 256 * VPL, UP = 64 * NL;
   static constexpr int ES = UP + 4;      // E row: y[UP], bl, mx, l2s, -
   static constexpr int RS = 2 * UP + 8;  // R row (recompute chain): the other side's lattice row in its HBM layout;
                                          // S row (main chain, in place): (s1, s2) per slot, s0 at [2 UP]
@@ -222,12 +222,12 @@ __device__ __forceinline__ void init_labels(S_t &S, const Problem &p, int b, int
     int tk = tok(i);
     S.norep[j] = (i == 0) || tk != tok(i - 1);
     S.norep_next[j] = tok(i + 1) != tk;
-    S.tokoff[j] = 4 * ((tk >= 0 && tk < p.V && tk < 256 && tk != p.blank) ? tk : 256);
+    S.tokoff[j] = 4 * ((tk >= 0 && tk < p.V && tk < S_t::V && tk != p.blank) ? tk : S_t::V);
     S.c[j] = NEG;
     S.o[j] = NEG;
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) S.mb[e] = (lane * 4 + e == p.blank) ? 1.f : 0.f;
+  for (int e = 0; e < 4 * (S_t::V / 256); ++e) S.mb[e] = (256 * (e / 4) + lane * 4 + (e & 3) == p.blank) ? 1.f : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -265,10 +265,10 @@ struct P1Split {
   }
 };
 
-template <int KIND, int NL, int NH, int BLK, int SIDE, int P0, int NQ, class S_t>
-__device__ __forceinline__ void estage1(const S_t &S, Lds<KIND, NL, NH, BLK> &lds, const Geo<BLK> &geo,
+template <int KIND, int NL, int NH, int BLK, int VPL, int SIDE, int P0, int NQ, class S_t>
+__device__ __forceinline__ void estage1(const S_t &S, Lds<KIND, NL, NH, BLK, VPL> &lds, const Geo<BLK> &geo,
                                         float2 *__restrict__ stats, float *dump, int lane, Stamps &st) {
-  using LD = Lds<KIND, NL, NH, BLK>;
+  using LD = Lds<KIND, NL, NH, BLK, VPL>;
   const int len = geo.len;
   const int nb = geo.nblocks(1, SIDE);
   auto write_E = [&](float *row, const Emis<NL> &e) __attribute__((always_inline)) {
@@ -287,10 +287,10 @@ __device__ __forceinline__ void estage1(const S_t &S, Lds<KIND, NL, NH, BLK> &ld
     return t < 0 ? 0 : t;
   };
   constexpr int NQA = NQ > 0 ? NQ : 1;
-  float4 xb[NQA][1];
+  float4 xb[NQA][VPL];
   static_for<0, NQA>([&](auto Q) {
     constexpr int q = decltype(Q)::value;
-    xb[q][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    static_for<0, VPL>([&](auto W) { xb[q][decltype(W)::value] = make_float4(0.f, 0.f, 0.f, 0.f); });
     if (NQ > 0 && nb > 0) S.load_x(xb[q], fr(0, P0 + q));
   });
   for (int it = 0; it <= geo.NB; ++it) {
@@ -302,11 +302,14 @@ __device__ __forceinline__ void estage1(const S_t &S, Lds<KIND, NL, NH, BLK> &ld
       float smx = 0.f, sl2 = 0.f;  // lane d keeps the statistics of position d of the block
       if (nv == BLK) {
         if constexpr (NQ > 0) {
-          float4 xq[NQA][1];
+          float4 xq[NQA][VPL];
           Emis<NL> e[NQA];
           static_for<0, NQA>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
-            xq[q][0] = make_float4(xb[q][0].x, xb[q][0].y, xb[q][0].z, xb[q][0].w);
+            static_for<0, VPL>([&](auto W) {
+              constexpr int w = decltype(W)::value;
+              xq[q][w] = make_float4(xb[q][w].x, xb[q][w].y, xb[q][w].z, xb[q][w].w);
+            });
           });
           S.template emit_n<NQA>(xq, e);  // NQ frames in one batch
           static_for<0, NQA>([&](auto Q) {
@@ -320,7 +323,7 @@ __device__ __forceinline__ void estage1(const S_t &S, Lds<KIND, NL, NH, BLK> &ld
         for (int q = 0; q < NQ; ++q) {
           const int d = P0 + q;
           if (d < nv) {
-            float4 xr[1];
+            float4 xr[VPL];
             S.load_x(xr, geo.frame(SIDE, g, d));
             Emis<NL> e;
             S.emit(xr, 0, e);
@@ -345,13 +348,13 @@ __device__ __forceinline__ void estage1(const S_t &S, Lds<KIND, NL, NH, BLK> &ld
 // ------------------------------------------------------------------------------------------------
 // main chain
 // ------------------------------------------------------------------------------------------------
-template <int KIND, int NL, int NH, int BLK, int DIR>
+template <int KIND, int NL, int NH, int BLK, int VPL, int DIR>
 __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, float *__restrict__ alpha_ws,
                                          float *__restrict__ beta_ws, double *__restrict__ logp_ws,
-                                         float *__restrict__ loss, Lds<KIND, NL, NH, BLK> &lds, const Geo<BLK> &geo,
+                                         float *__restrict__ loss, Lds<KIND, NL, NH, BLK, VPL> &lds, const Geo<BLK> &geo,
                                          void *stamp_ws, bool want_grad) {
-  using S_t = Side<KIND, NL, 1, DIR, true>;
-  using LD = Lds<KIND, NL, NH, BLK>;
+  using S_t = Side<KIND, NL, VPL, DIR, true>;
+  using LD = Lds<KIND, NL, NH, BLK, VPL>;
   S_t S;
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x;
@@ -484,14 +487,14 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
 //   SIDE B classic (needs alpha[t+1] at t = BLK g + nv-1-d): step frames upward from alpha[BLK g], row after each step
 //   SIDE B simplified (needs a[t])                        : row before each step
 // ------------------------------------------------------------------------------------------------
-template <int KIND, int NL, int NH, int BLK, int SIDE, int XT>
+template <int KIND, int NL, int NH, int BLK, int VPL, int SIDE, int XT>
 __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L, const float *__restrict__ alpha_ws,
                                               const float *__restrict__ beta_ws, float2 *__restrict__ stats_ws,
-                                              Lds<KIND, NL, NH, BLK> &lds, const Geo<BLK> &geo, void *stamp_ws,
+                                              Lds<KIND, NL, NH, BLK, VPL> &lds, const Geo<BLK> &geo, void *stamp_ws,
                                               bool want_grad) {
   constexpr int RDIR = 1 - SIDE;  // direction of the recursion this wave runs
-  using S_t = Side<KIND, NL, 1, RDIR, true, XT>;
-  using LD = Lds<KIND, NL, NH, BLK>;
+  using S_t = Side<KIND, NL, VPL, RDIR, true, XT>;
+  using LD = Lds<KIND, NL, NH, BLK, VPL>;
   S_t S;
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x;
@@ -515,9 +518,9 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
     S.xst = p.xst;
     S.Vr = p.V;
     S.xs = lds.xcopy_r[SIDE];
-    if (lane == 0) S.xs[256] = -6.0e29f;  // pad slot of the gather copy: "log 0" for label positions beyond label_length
+    if (lane == 0) S.xs[256 * VPL] = -6.0e29f;  // pad slot of the gather copy: "log 0" for label positions beyond label_length
     float2 *stats = stats_ws + (long)b * T;
-    estage1<KIND, NL, NH, BLK, SIDE, SP::first(NH), SP::count(NH)>(S, lds, geo, stats, dump, lane, st);
+    estage1<KIND, NL, NH, BLK, VPL, SIDE, SP::first(NH), SP::count(NH)>(S, lds, geo, stats, dump, lane, st);
   }
   STAMP(st.phase1_done());
   __syncthreads();
@@ -594,14 +597,14 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
 // ------------------------------------------------------------------------------------------------
 // helper wavefront h of NH per side: positions d = h, h + NH, ... of every block (FPH = BLK / NH per block)
 // ------------------------------------------------------------------------------------------------
-template <int KIND, int NL, int NH, int BLK, int DIR, int XT>
+template <int KIND, int NL, int NH, int BLK, int VPL, int DIR, int XT>
 __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, float2 *__restrict__ stats_ws,
                                            const float *__restrict__ d_loss, float *__restrict__ grad,
-                                           Lds<KIND, NL, NH, BLK> &lds, const Geo<BLK> &geo, int h, void *stamp_ws) {
-  constexpr int V = 256;
+                                           Lds<KIND, NL, NH, BLK, VPL> &lds, const Geo<BLK> &geo, int h, void *stamp_ws) {
+  constexpr int V = 256 * VPL;
   constexpr int FPH = BLK / NH;
-  using S_t = Side<KIND, NL, 1, DIR, true, XT>;
-  using LD = Lds<KIND, NL, NH, BLK>;
+  using S_t = Side<KIND, NL, VPL, DIR, true, XT>;
+  using LD = Lds<KIND, NL, NH, BLK, VPL>;
   S_t S;
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x;
@@ -653,14 +656,14 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
     using SP = P1Split<BLK, NH, NL>;
     if constexpr (NH == 4) {
       switch (h) {
-        case 0: estage1<KIND, NL, NH, BLK, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, dump, lane, st); break;
-        case 1: estage1<KIND, NL, NH, BLK, DIR, SP::first(1), SP::count(1)>(S, lds, geo, stats, dump, lane, st); break;
-        case 2: estage1<KIND, NL, NH, BLK, DIR, SP::first(2), SP::count(2)>(S, lds, geo, stats, dump, lane, st); break;
-        default: estage1<KIND, NL, NH, BLK, DIR, SP::first(3), SP::count(3)>(S, lds, geo, stats, dump, lane, st); break;
+        case 0: estage1<KIND, NL, NH, BLK, VPL, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, dump, lane, st); break;
+        case 1: estage1<KIND, NL, NH, BLK, VPL, DIR, SP::first(1), SP::count(1)>(S, lds, geo, stats, dump, lane, st); break;
+        case 2: estage1<KIND, NL, NH, BLK, VPL, DIR, SP::first(2), SP::count(2)>(S, lds, geo, stats, dump, lane, st); break;
+        default: estage1<KIND, NL, NH, BLK, VPL, DIR, SP::first(3), SP::count(3)>(S, lds, geo, stats, dump, lane, st); break;
       }
     } else {
-      if (h == 0) estage1<KIND, NL, NH, BLK, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, dump, lane, st);
-      else estage1<KIND, NL, NH, BLK, DIR, SP::first(1), SP::count(1)>(S, lds, geo, stats, dump, lane, st);
+      if (h == 0) estage1<KIND, NL, NH, BLK, VPL, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, dump, lane, st);
+      else estage1<KIND, NL, NH, BLK, VPL, DIR, SP::first(1), SP::count(1)>(S, lds, geo, stats, dump, lane, st);
     }
   }
 
@@ -686,11 +689,13 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
     // COMPILE time -- the loop is unrolled by five -- instead of being moved from set to set every block (48 v_mov per
     // block, 7 % of the phase-2 instructions of a helper).  The statistics of a block travel the same way.
     constexpr int RING = 5;
-    float4 X[RING][FPH][1];
+    float4 X[RING][FPH][VPL];
     float2 SG[RING];
     static_for<0, RING>([&](auto R) {
       SG[decltype(R)::value] = make_float2(0.f, 0.f);
-      static_for<0, FPH>([&](auto Q) { X[decltype(R)::value][decltype(Q)::value][0] = make_float4(0.f, 0.f, 0.f, 0.f); });
+      static_for<0, FPH>([&](auto Q) {
+        static_for<0, VPL>([&](auto W) { X[decltype(R)::value][decltype(Q)::value][decltype(W)::value] = make_float4(0.f, 0.f, 0.f, 0.f); });
+      });
     });
     float2 st_cur = make_float2(0.f, 0.f), st_next = make_float2(0.f, 0.f);
     if (nb > 0) {
@@ -723,7 +728,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
           });
         } else {
           for (int d = h; d < nv; d += NH) {
-            float4 xr[1];
+            float4 xr[VPL];
             S.load_x(xr, geo.frame(DIR, g, d));
             float2 sd = stats[geo.frame(DIR, g, d)];
             Emis<NL> e;
@@ -744,7 +749,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         const int g = geo.absblock(2, DIR, gj);
         const int nv = geo.nvof(g);
         const float(*SR)[LD::RS] = lds.R[DIR][gj % 3];
-        auto g_frame = [&](int d, const float4(&xr)[1], float mx, float l2s) __attribute__((always_inline)) {
+        auto g_frame = [&](int d, const float4(&xr)[VPL], float mx, float l2s) __attribute__((always_inline)) {
           const float *row = SR[d];
           float s1[NL], s2[NL];
           ld_pairs<NL>(row + 2 * lane * NL, s1, s2);
@@ -765,7 +770,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
           });
         } else {
           for (int d = h; d < nv; d += NH) {
-            float4 xr[1];
+            float4 xr[VPL];
             S.load_x(xr, geo.frame(DIR, g, d));
             float2 sd = stats[geo.frame(DIR, g, d)];
             g_frame(d, xr, sd.x, sd.y);
@@ -786,7 +791,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
 }
 
 // Wavefront roles: 0 main A, 1 main B, 2 recompute for A, 3 recompute for B, then NH helpers of A, NH helpers of B.
-template <int KIND, int NL, int NH, int BLK, int XT>
+template <int KIND, int NL, int NH, int BLK, int VPL, int XT>
 __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused5_kernel(Problem p, Layout L, float *__restrict__ alpha_ws,
                                                                     float *__restrict__ beta_ws,
                                                                     double *__restrict__ logp_ws,
@@ -794,48 +799,48 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused5_kernel(Problem p, La
                                                                     float *__restrict__ loss,
                                                                     const float *__restrict__ d_loss,
                                                                     float *__restrict__ grad, void *stamp_ws) {
-  __shared__ __attribute__((aligned(16))) Lds<KIND, NL, NH, BLK> lds;
+  __shared__ __attribute__((aligned(16))) Lds<KIND, NL, NH, BLK, VPL> lds;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps everything derived from it in SGPRs
   Geo<BLK> geo;  // every wavefront derives the same block schedule: the barrier counts match by construction
   geo.init(clampi(p.logit_length[blockIdx.x], 0, p.T));
   if (w == 0) {
     __builtin_amdgcn_s_setprio(3);  // the sequential chains win issue arbitration against co-resident helpers
-    run_main<KIND, NL, NH, BLK, 0>(p, L, alpha_ws, beta_ws, logp_ws, loss, lds, geo, stamp_ws, grad != nullptr);
+    run_main<KIND, NL, NH, BLK, VPL, 0>(p, L, alpha_ws, beta_ws, logp_ws, loss, lds, geo, stamp_ws, grad != nullptr);
   } else if (w == 1) {
     __builtin_amdgcn_s_setprio(3);
-    run_main<KIND, NL, NH, BLK, 1>(p, L, alpha_ws, beta_ws, logp_ws, loss, lds, geo, stamp_ws, grad != nullptr);
+    run_main<KIND, NL, NH, BLK, VPL, 1>(p, L, alpha_ws, beta_ws, logp_ws, loss, lds, geo, stamp_ws, grad != nullptr);
   } else if (w == 2) {
     __builtin_amdgcn_s_setprio(2);
-    run_recompute<KIND, NL, NH, BLK, 0, XT>(p, L, alpha_ws, beta_ws, stats_ws, lds, geo, stamp_ws, grad != nullptr);
+    run_recompute<KIND, NL, NH, BLK, VPL, 0, XT>(p, L, alpha_ws, beta_ws, stats_ws, lds, geo, stamp_ws, grad != nullptr);
   } else if (w == 3) {
     __builtin_amdgcn_s_setprio(2);
-    run_recompute<KIND, NL, NH, BLK, 1, XT>(p, L, alpha_ws, beta_ws, stats_ws, lds, geo, stamp_ws, grad != nullptr);
+    run_recompute<KIND, NL, NH, BLK, VPL, 1, XT>(p, L, alpha_ws, beta_ws, stats_ws, lds, geo, stamp_ws, grad != nullptr);
   } else if (w < 4 + NH) {
-    run_helper<KIND, NL, NH, BLK, 0, XT>(p, L, stats_ws, d_loss, grad, lds, geo, w - 4, stamp_ws);
+    run_helper<KIND, NL, NH, BLK, VPL, 0, XT>(p, L, stats_ws, d_loss, grad, lds, geo, w - 4, stamp_ws);
   } else {
-    run_helper<KIND, NL, NH, BLK, 1, XT>(p, L, stats_ws, d_loss, grad, lds, geo, w - 4 - NH, stamp_ws);
+    run_helper<KIND, NL, NH, BLK, VPL, 1, XT>(p, L, stats_ws, d_loss, grad, lds, geo, w - 4 - NH, stamp_ws);
   }
 }
 
 }  // namespace fused5
 
-template <int NL, int NH, int BLK>
+template <int NL, int NH, int BLK, int VPL>
 static hipError_t launch5(const Problem &p, const Layout &L, float *a, float *b, double *lp, float2 *stats, float *loss,
                           const float *d_loss, float *grad, void *stamp, hipStream_t st) {
-  static_assert(sizeof(fused5::Lds<CTC_FUSED_KIND, NL, NH, BLK>) <= 160 * 1024, "LDS budget of one CU");
-  const bool plain = p.xdtype == 0 && p.V == 256 && p.xst == 256 && p.gst == 256;  // frame stride folded into the addressing
+  static_assert(sizeof(fused5::Lds<CTC_FUSED_KIND, NL, NH, BLK, VPL>) <= 160 * 1024, "LDS budget of one CU");
+  const bool plain = p.xdtype == 0 && p.V == 256 * VPL && p.xst == p.V && p.gst == p.V;  // frame stride folded into the addressing
   const dim3 grid(p.B), block(64 * (4 + 2 * NH));
   if (plain)
-    hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, 0>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
+    hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 0>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
                        d_loss, grad, stamp);
   else if (p.xdtype == 0 && ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0)
-    hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, 1>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
+    hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 1>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
                        d_loss, grad, stamp);
   else if (p.xdtype == 0)  // vocabulary or strides not a multiple of 4 elements: element-wise row accesses
-    hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, 3>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
+    hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 3>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
                        d_loss, grad, stamp);
   else
-    hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, 2>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
+    hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 2>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
                        d_loss, grad, stamp);
   return hipGetLastError();
 }
@@ -852,10 +857,15 @@ hipError_t run_fused5_simplified
   float2 *stats = reinterpret_cast<float2 *>(ws + L.off_emis);  // the emission region of the v1 pipeline is free here
   void *stamp = ws + L.off_dummy;  // diagnostic builds (-DCTC_FUSED_STAMPS) write per-wavefront cycle counts here
   switch (L.NL) {
-    case 1: return launch5<1, 4, 12>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
-    case 2: return launch5<2, 4, 12>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
+    // vocabularies of 257 .. 512 tokens: two 16-byte segments of the logits row per lane (VPL = 2); the five-block ring of
+    // logits rows then needs the 256-register budget of the 8-wavefront configuration (6-frame blocks, two helpers a side)
+    case 1: return p.V <= 256 ? launch5<1, 4, 12, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st)
+                              : launch5<1, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
+    case 2: return p.V <= 256 ? launch5<2, 4, 12, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st)
+                              : launch5<2, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
     // 129 .. 256 label positions: four per lane; rows are twice as long, so 6-frame blocks and two helpers per side
-    case 4: return launch5<4, 2, 6>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
+    case 4: return p.V <= 256 ? launch5<4, 2, 6, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st)
+                              : launch5<4, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
     default: return hipErrorInvalidValue;
   }
 }
