@@ -18,6 +18,8 @@ for T in (1, 2, 11, 12, 13, 23, 24, 25, 35, 36, 37, 47, 48, 49, 97, 240):
     CASES.append((T, U, V, int(_rng.integers(1, 6))))
 for U in (0, 1, 2, 63, 64, 65, 127, 128, 129, 200):
     CASES.append((int(_rng.integers(U + 1, 2 * U + 40)), U, int(_rng.choice([12, 31, 256])), 4))
+# four label positions per lane x two row segments per lane, and the 8-wavefront configuration at its limits
+CASES += [(300, 200, 512, 3), (420, 256, 300, 2), (64, 20, 512, 5), (13, 3, 260, 4), (600, 256, 512, 2)]
 
 
 @pytest.mark.parametrize("kind", ["classic", "simplified"])
