@@ -12,8 +12,10 @@ hipError_t run_grad(const Problem &p, const Layout &L, char *ws, const float *d_
 hipError_t run_convert(const Problem &p, const Layout &L, char *ws, float *alpha_out, float *beta_out, hipStream_t st);
 hipError_t run_fused_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 hipError_t run_fused_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
-hipError_t run_fused5_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
-hipError_t run_fused5_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
+#define CTC_F5_DECL(name) hipError_t name(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st)
+CTC_F5_DECL(run_fused5_classic_nl1); CTC_F5_DECL(run_fused5_classic_nl2); CTC_F5_DECL(run_fused5_classic_nl4);
+CTC_F5_DECL(run_fused5_simplified_nl1); CTC_F5_DECL(run_fused5_simplified_nl2); CTC_F5_DECL(run_fused5_simplified_nl4);
+#undef CTC_F5_DECL
 // shapes the checkpoint + recompute kernel (ctc_fused5.hip) is instantiated for: logits input, V <= 512 (smaller
 // vocabularies run with the lanes beyond V masked; V or strides not a multiple of 4: element-wise row accesses), U <= 256
 inline bool plain_format(const Problem &p) {  // contiguous float32 [B,T,V] logits and gradient
@@ -26,7 +28,12 @@ inline bool fused5_eligible(const Problem &p, const Layout &L) {
          (p.xdtype == 0 || ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0);
 }
 inline hipError_t run_fused5(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
-  return p.kind == 0 ? run_fused5_classic(p, L, ws, loss, d_loss, grad, st) : run_fused5_simplified(p, L, ws, loss, d_loss, grad, st);
+  switch (L.NL) {  // one translation unit of ctc_fused5.hip per (kind, label positions per lane)
+    case 1: return p.kind == 0 ? run_fused5_classic_nl1(p, L, ws, loss, d_loss, grad, st) : run_fused5_simplified_nl1(p, L, ws, loss, d_loss, grad, st);
+    case 2: return p.kind == 0 ? run_fused5_classic_nl2(p, L, ws, loss, d_loss, grad, st) : run_fused5_simplified_nl2(p, L, ws, loss, d_loss, grad, st);
+    case 4: return p.kind == 0 ? run_fused5_classic_nl4(p, L, ws, loss, d_loss, grad, st) : run_fused5_simplified_nl4(p, L, ws, loss, d_loss, grad, st);
+    default: return hipErrorInvalidValue;
+  }
 }
 hipError_t run_fused4_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 hipError_t run_fused4_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);

@@ -845,29 +845,36 @@ static hipError_t launch5(const Problem &p, const Layout &L, float *a, float *b,
   return hipGetLastError();
 }
 
-#if CTC_FUSED_KIND == 0
-hipError_t run_fused5_classic
-#else
-hipError_t run_fused5_simplified
+// One translation unit per (lattice kind, label positions per lane): -DCTC_FUSED_KIND=0|1 -DCTC_FUSED5_NL=1|2|4 (the
+// instantiations are large; split like this they compile in parallel).  Exported: run_fused5_<kind>_nl<NL>.
+#ifndef CTC_FUSED5_NL
+#error "compile with -DCTC_FUSED5_NL=1, 2 or 4"
 #endif
-    (const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
+#define CTC_F5_CAT2(a, b, c) a##b##c
+#define CTC_F5_CAT(a, b, c) CTC_F5_CAT2(a, b, c)
+#if CTC_FUSED_KIND == 0
+#define CTC_F5_ENTRY CTC_F5_CAT(run_fused5_classic, _nl, CTC_FUSED5_NL)
+#else
+#define CTC_F5_ENTRY CTC_F5_CAT(run_fused5_simplified, _nl, CTC_FUSED5_NL)
+#endif
+hipError_t CTC_F5_ENTRY(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad,
+                        hipStream_t st) {
   float *alpha = reinterpret_cast<float *>(ws + L.off_alpha);
   float *beta = reinterpret_cast<float *>(ws + L.off_beta);
   double *logp = reinterpret_cast<double *>(ws + L.off_logp);
   float2 *stats = reinterpret_cast<float2 *>(ws + L.off_emis);  // the emission region of the v1 pipeline is free here
   void *stamp = ws + L.off_dummy;  // diagnostic builds (-DCTC_FUSED_STAMPS) write per-wavefront cycle counts here
-  switch (L.NL) {
-    // vocabularies of 257 .. 512 tokens: two 16-byte segments of the logits row per lane (VPL = 2); the five-block ring of
-    // logits rows then needs the 256-register budget of the 8-wavefront configuration (6-frame blocks, two helpers a side)
-    case 1: return p.V <= 256 ? launch5<1, 4, 12, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st)
-                              : launch5<1, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
-    case 2: return p.V <= 256 ? launch5<2, 4, 12, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st)
-                              : launch5<2, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
-    // 129 .. 256 label positions: four per lane; rows are twice as long, so 6-frame blocks and two helpers per side
-    case 4: return p.V <= 256 ? launch5<4, 2, 6, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st)
-                              : launch5<4, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
-    default: return hipErrorInvalidValue;
-  }
+  if (L.NL != CTC_FUSED5_NL) return hipErrorInvalidValue;
+  // Vocabularies of 257 .. 512 tokens: two 16-byte segments of the logits row per lane (VPL = 2); the five-block ring of
+  // logits rows then needs the 256-register budget of the 8-wavefront configuration (6-frame blocks, two helpers a side).
+  // 129 .. 256 label positions (four per lane): the LDS rows are twice as long -- the 8-wavefront configuration as well.
+#if CTC_FUSED5_NL == 4
+  return p.V <= 256 ? launch5<4, 2, 6, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st)
+                    : launch5<4, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
+#else
+  return p.V <= 256 ? launch5<CTC_FUSED5_NL, 4, 12, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st)
+                    : launch5<CTC_FUSED5_NL, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
+#endif
 }
 
 }  // namespace ctc
