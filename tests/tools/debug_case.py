@@ -1,5 +1,6 @@
+"""Diagnostic (test infrastructure: uses the oracle): one tiny case printed side by side, HIP path vs oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import tf_seq2seq_losses_amd as ctc
 from oracle import ctc_oracle as O

@@ -1,8 +1,9 @@
 """Diagnostic: HVP kernel vs dense Hessian contraction vs float64 central differences (C oracle gradient)."""
+import os
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import c_oracle as C
 from oracle import ctc_oracle as O
 from tf_seq2seq_losses_amd import ops, _lib
