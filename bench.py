@@ -274,7 +274,7 @@ def main():
             "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "f32 arithmetic, bf16 logits/gradient in HBM", "data": "synthetic",
-            "config": {"workload": f"{args.kind}_ctc_loss {'hessian' if args.hessian else 'loss+grad'} B={B} T={T} U={U} V={V} fp32 per GPU"
+            "config": {"workload": f"{args.kind}_ctc_loss {'hessian' if args.hessian else 'loss+grad'} B={B} T={T} U={U} V={V} {'fp32' if args.dtype == 'f32' else 'bf16 logits/gradient, fp32 arithmetic'} per GPU"
                                    + (" ragged" if args.ragged else " full-length") + (" time-major [T,B,V]" if args.time_major else ""),
                        "global_batch": B * world, "parallelism": f"batch-sharded x{world}, all-reduce of sum(loss)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
