@@ -20,6 +20,8 @@ for U in (0, 1, 2, 63, 64, 65, 127, 128, 129, 200):
     CASES.append((int(_rng.integers(U + 1, 2 * U + 40)), U, int(_rng.choice([12, 31, 256])), 4))
 # four label positions per lane x two row segments per lane, and the 8-wavefront configuration at its limits
 CASES += [(300, 200, 512, 3), (420, 256, 300, 2), (64, 20, 512, 5), (13, 3, 260, 4), (600, 256, 512, 2)]
+# four row segments per lane (513 .. 1024 tokens): the G stage re-reads its logits rows
+CASES += [(150, 100, 1024, 3), (77, 30, 700, 4), (40, 128, 1021, 2), (260, 64, 516, 2)]
 
 
 @pytest.mark.parametrize("kind", ["classic", "simplified"])

@@ -24,7 +24,7 @@ inline bool plain_format(const Problem &p) {  // contiguous float32 [B,T,V] logi
 inline bool fused5_eligible(const Problem &p, const Layout &L) {
   // producer formats: both tensors float32 or both bfloat16, strides keeping the 16-byte (8-byte) row accesses aligned
   // (bfloat16 needs 8-byte aligned rows: V and the strides multiples of 4; float32 takes any V <= 256 and any stride)
-  return p.wrt == 0 && p.V <= 512 && L.NL <= 4 && p.B > 0 && p.T > 0 && p.xdtype == p.gdtype &&
+  return p.wrt == 0 && (p.V <= 512 || (p.V <= 1024 && L.NL <= 2)) && L.NL <= 4 && p.B > 0 && p.T > 0 && p.xdtype == p.gdtype &&
          (p.xdtype == 0 || ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0);
 }
 inline hipError_t run_fused5(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {

@@ -688,9 +688,15 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
     // later: five blocks are alive at a time.  They sit in a ring of five register sets addressed by (block mod 5) at
     // COMPILE time -- the loop is unrolled by five -- instead of being moved from set to set every block (48 v_mov per
     // block, 7 % of the phase-2 instructions of a helper).  The statistics of a block travel the same way.
-    constexpr int RING = 5;
+    // Wide vocabularies (four row segments per lane) cannot afford five register sets: there the ring holds the block in
+    // its E stage and the one being loaded, and the G stage re-reads its rows and statistics (L2 hits) at the top of the
+    // iteration.
+    constexpr bool RELOAD = VPL >= 4;
+    constexpr int RING = RELOAD ? 2 : 5;
     float4 X[RING][FPH][VPL];
+    float4 XG[RELOAD ? FPH : 1][VPL];
     float2 SG[RING];
+    float2 sgl = make_float2(0.f, 0.f);
     static_for<0, RING>([&](auto R) {
       SG[decltype(R)::value] = make_float2(0.f, 0.f);
       static_for<0, FPH>([&](auto Q) {
@@ -703,9 +709,13 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
       st_cur = stats[fr(2, 0, lane)];
     }
     auto body = [&](auto R, int it) __attribute__((always_inline)) {
-      constexpr int r = decltype(R)::value;         // = it mod 5
+      constexpr int r = decltype(R)::value;         // = it mod RING
       constexpr int rn = (r + 1) % RING;            // block it+1 (being loaded)
-      constexpr int rg = (r + 2) % RING;            // block it-3 (G stage)
+      constexpr int rg = (r + 2) % RING;            // block it-3 (G stage; five-set ring only)
+      if constexpr (RELOAD) {
+        static_for<0, FPH>([&](auto Q) { S.load_x(XG[decltype(Q)::value], fr(2, it - 3, h + NH * decltype(Q)::value)); });
+        sgl = stats[fr(2, it - 3, lane)];
+      }
       // ---- E stage (block it) ----
       const int j = it;
       SG[r] = st_cur;
@@ -766,7 +776,8 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
           static_for<0, FPH>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             const int d = h + NH * q;
-            g_frame(d, X[rg][q], readlane_f(SG[rg].x, d), readlane_f(SG[rg].y, d));
+            if constexpr (RELOAD) g_frame(d, XG[q], readlane_f(sgl.x, d), readlane_f(sgl.y, d));
+            else g_frame(d, X[rg][q], readlane_f(SG[rg].x, d), readlane_f(SG[rg].y, d));
           });
         } else {
           for (int d = h; d < nv; d += NH) {
@@ -868,12 +879,14 @@ hipError_t CTC_F5_ENTRY(const Problem &p, const Layout &L, char *ws, float *loss
   // Vocabularies of 257 .. 512 tokens: two 16-byte segments of the logits row per lane (VPL = 2); the five-block ring of
   // logits rows then needs the 256-register budget of the 8-wavefront configuration (6-frame blocks, two helpers a side).
   // 129 .. 256 label positions (four per lane): the LDS rows are twice as long -- the 8-wavefront configuration as well.
+  // 513 .. 1024 tokens: four segments per lane; the G stage re-reads its logits rows (no room for the five-block ring).
 #if CTC_FUSED5_NL == 4
   return p.V <= 256 ? launch5<4, 2, 6, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st)
                     : launch5<4, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
 #else
-  return p.V <= 256 ? launch5<CTC_FUSED5_NL, 4, 12, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st)
-                    : launch5<CTC_FUSED5_NL, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
+  return p.V <= 256   ? launch5<CTC_FUSED5_NL, 4, 12, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st)
+         : p.V <= 512 ? launch5<CTC_FUSED5_NL, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st)
+                      : launch5<CTC_FUSED5_NL, 2, 6, 4>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, st);
 #endif
 }
 
