@@ -142,8 +142,11 @@ __device__ __forceinline__ void store_singles(float *__restrict__ row, int lane,
   }
 }
 
-constexpr int PF = 16;       // emission rows kept in flight per wave (= steps of one unrolled block)
-constexpr int RENORM = 16;   // steps between exact renormalisations of the lattice row (== PF: static position)
+// emission rows kept in flight per wave (= steps of one unrolled block = steps between exact renormalisations of the
+// lattice row).  Fewer for long labels, whose rows fill the register file (16 rows of 16 positions per lane spilled
+// 1256 VGPRs).
+template <int NL>
+struct ScanCfg { static constexpr int PF = NL <= 2 ? 16 : (NL == 4 ? 8 : (NL == 8 ? 4 : 2)); };
 
 // One wavefront: blockIdx.x = utterance; DIR 0 = alpha (forward in t), 1 = beta (backward).
 // Slot i = lane*NL + j is label position i (token label[i]).
@@ -323,6 +326,7 @@ __device__ __forceinline__ void scan_body(const Problem &p, const Layout &L, con
   if (len > 0) {
     int vz;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    constexpr int PF = ScanCfg<NL>::PF, RENORM = PF;
     ERow<NL> buf[PF];
 #pragma unroll
     for (int d = 0; d < PF; ++d) load_erow<NL>(buf[d], erow_ptr(d), lane, UP, vz);
