@@ -59,3 +59,31 @@ def test_loss_grad_in_a_hip_graph(kind, V, U):
         assert np.array_equal(np.isfinite(loss.cpu().numpy()), fin)
         assert np.abs(loss.cpu().numpy()[fin] - rl[fin]).max() < 1e-4 * max(1.0, np.abs(rl[fin]).max())
         assert np.abs(grad.cpu().numpy() - rg).max() < 1e-4
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_concurrent_calls_on_two_streams(kind):
+    """The library keeps no state: calls with distinct (stream, workspace) pairs may overlap."""
+    from tf_seq2seq_losses_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    k = ops.KINDS[kind]
+    B, T, V, U = 40, 300, 256, 60
+    rng = np.random.default_rng(5)
+    jobs = []
+    for i in range(2):
+        x = torch.from_numpy(rng.standard_normal((B, T, V)).astype(np.float32)).to(dev)
+        labels = torch.from_numpy(rng.integers(1, V, (B, U)).astype(np.int32)).to(dev)
+        ll = torch.from_numpy(rng.integers(0, U + 1, B).astype(np.int32)).to(dev)
+        tl = torch.from_numpy(rng.integers(T // 2, T + 1, B).astype(np.int32)).to(dev)
+        jobs.append(ops.Prepared(labels, x, ll, tl, 0))
+    ref = [ops.loss_grad(k, _lib.WRT_LOGITS, p, True) for p in jobs]       # one after the other
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [None, None]
+    for rep in range(3):                                                      # overlapped
+        for i, (p, s) in enumerate(zip(jobs, streams)):
+            with torch.cuda.stream(s):
+                outs[i] = ops.loss_grad(k, _lib.WRT_LOGITS, p, True)
+    torch.cuda.synchronize()
+    for (l0, g0), (l1, g1) in zip(ref, outs):
+        assert torch.equal(l0, l1) and torch.equal(g0, g1)
