@@ -258,12 +258,13 @@ def main():
             traffic = None
         else:
             pipeline = _lib.pipeline_name(kind, _lib.WRT_LOGITS, B, T, V, U, True)
-            kernel_name = {"fused5": "fused5_kernel (one launch: chains + recompute chains + helpers)",
-                           "fused4": "fused4_kernel", "fused2": "fused_kernel",
+            kernel_name = {"fused6": "fused6_kernel (one launch: linear-domain chains + recompute chains + helpers) + the fused5_kernel launch for flagged utterances (none here)",
+                           "fused5": "fused5_kernel (one launch: chains + recompute chains + helpers)",
+                           "fused2": "fused_kernel",
                            "v1": "emit_kernel + scan_kernel + grad_kernel"}[pipeline] + " = one ctc_amd_loss_grad call"
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "r01_fused5_pmc_traffic.json")
-            if pipeline == "fused5" and args.kind == "classic" and (B, T, U, V) == (256, 1000, 128, 256) and not args.ragged \
+            if pipeline == "fused5x" and args.kind == "classic" and (B, T, U, V) == (256, 1000, 128, 256) and not args.ragged \
                     and args.dtype == "f32" and not args.time_major \
                     and os.path.exists(tfile):
                 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file's note)

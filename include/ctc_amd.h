@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CTC_AMD_ABI_VERSION 1
+#define CTC_AMD_ABI_VERSION 2
 
 /* lattice variant */
 #define CTC_AMD_CLASSIC 0    /* classic_ctc_loss.py:33-70   (collapse repeats, then drop blanks)   */
@@ -68,9 +68,17 @@ int ctc_amd_abi_version(void);
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char *ctc_amd_last_error(void);
 
-/* Name of the kernel pipeline ctc_amd_loss_grad would run for these shapes ("fused5", "fused4", "fused2" or "v1");
- * diagnostic only (benchmarks and tests report it), never needed for correctness. */
+/* Name of the kernel pipeline ctc_amd_loss_grad would run for contiguous float32 tensors of these shapes ("fused6",
+ * "fused5", "fused2" or "v1"); diagnostic only (benchmarks and tests report it), never needed for correctness. */
 const char *ctc_amd_pipeline_name(int kind, int wrt, int B, int T, int V, int U, int want_grad);
+
+/*
+ * Diagnostic override, for parity tests and benchmarks only (process-wide; set it between calls, not during one):
+ *   key "pipeline": "" (best eligible tier, default), "v1", "fused2", "fused5" -- forces a lower tier of ctc_amd_loss_grad
+ *   key "hessian":  "" (default) or "slab" -- the general Hessian kernel also for labels of <= 32 positions
+ * The library never reads the environment.  Returns CTC_AMD_EINVAL for an unknown key or value.
+ */
+int ctc_amd_debug_override(const char *key /*host*/, const char *value /*host*/);
 
 /* Bytes of device workspace the call selected by `what` needs for these shapes. */
 int ctc_amd_workspace_bytes(int what, int kind, int B, int T, int V, int U, size_t *out_bytes /*host*/);

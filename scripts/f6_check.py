@@ -1,0 +1,144 @@
+"""Diagnostic: the default tier (fused6 + fused5 fallback) against the float64 C oracle over a set of shapes; prints the
+error, the number of utterances fused6 flagged (read back from the workspace) and the time per call."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes
+import numpy as np
+import torch
+from oracle import c_oracle as C
+from tf_seq2seq_losses_amd import _lib, ops
+
+dev = torch.device("cuda:0")
+
+
+def flags_of(ws, kind, B, T, V, U):
+    # Layout::off_flags: recompute the offsets like make_layout (ctc_common.h)
+    al = lambda x: (x + 255) & ~255
+    nl = 1
+    while nl * 64 < U:
+        nl *= 2
+    UP = nl * 64; ERS = UP + 4; SRS = (2 * UP if kind == 0 else UP) + 8
+    o = 0
+    o = al(o + B * T * ERS * 4); o = al(o + B * (T + 1) * SRS * 4); o = al(o + B * (T + 1) * SRS * 4)
+    o = al(o + B * 8); o = al(o + B * 2 * 1024); o = al(o + B * 4)
+    o = al(o + B * 2 * ((T + 5) // 6 + 3) * 64 * 4)
+    if os.environ.get("F6_STAMPS"):
+        st = ws[o + 4 * B:o + 4 * B + B * 512].view(torch.int64).cpu().numpy().reshape(B, 16, 4)[:, :12]
+        med = np.median(st, axis=0)
+        names = ["main A", "main B", "rec A", "rec B"] + [f"help A{i}" for i in range(4)] + [f"help B{i}" for i in range(4)]
+        print("   per-wave cycles (median over utterances):   phase1 work / wait     phase2 work / wait")
+        for w in range(12):
+            print(f"     {names[w]:8s} {med[w, 0]:9.0f} {med[w, 1]:9.0f}   {med[w, 2]:9.0f} {med[w, 3]:9.0f}")
+    if os.environ.get("F6_DEBUG2"):
+        dbg = ws[o + 4 * B:o + 4 * B + B * 2048 * 4].view(torch.int32).cpu().numpy().reshape(B, 2048)[0].reshape(4, 8, 64)
+        for d in range(4):
+            f = dbg[d].view(np.float32)
+            tot = f[0].astype(np.float64).sum() + f[1].astype(np.float64).sum() + f[2].astype(np.float64).sum()
+            print(f"   d={d}: total mass {tot / 2**30:.6f}  qb {f[0][:8].tolist()} qt0 {f[1][:8].tolist()} qt1 {f[2][:8].tolist()}")
+            print(f"        S.k {dbg[d, 3][:8].tolist()} kR {dbg[d, 4][:8].tolist()} ra0 {f[5][:8].tolist()} ra1 {f[6][:8].tolist()} c0 {f[7][:8].tolist()}")
+            big = np.argsort(-(f[0] + f[1] + f[2]))[:6]
+            print(f"        heaviest lanes {big.tolist()} mass {((f[0] + f[1] + f[2])[big] / 2**30).tolist()}")
+        hd = ws[o + 4 * B:o + 4 * B + B * 2048 * 4].view(torch.int32).cpu().numpy().reshape(B, 2048)[0][1024:1024 + 192].reshape(3, 64).view(np.float32)
+        md = dbg[1].view(np.float32)
+        print("   helper-1 read of d=1 equals what main wrote:", np.array_equal(hd[0], md[0]), np.array_equal(hd[1], md[1]), np.array_equal(hd[2], md[2]))
+        bad = np.nonzero((hd[0] != md[0]) | (hd[1] != md[1]) | (hd[2] != md[2]))[0]
+        print("   differing lanes", bad.tolist()[:20], "helper", hd[:, bad[:6]].tolist(), "main", md[:3, bad[:6]].tolist())
+    if os.environ.get("F6_DEBUG"):
+        fl = ws[o:o + 4 * B].view(torch.int32).cpu().numpy()
+        dbg = ws[o + 4 * B:o + 4 * B + B * 2048 * 4].view(torch.int32).cpu().numpy().reshape(B, 2048)[:, :512].reshape(B, 2, 4, 64)
+        shown = 0
+        for b in np.nonzero(fl)[0]:
+            for d in range(2):
+                lanes = np.nonzero(dbg[b, d, 0])[0]
+                if len(lanes) and shown < 12:
+                    shown += 1
+                    print(f"   b={b} dir={d} flag={hex(fl[b])} dead lanes {lanes.tolist()} renorm# {dbg[b, d, 0, lanes].tolist()} k_before {dbg[b, d, 1, lanes].tolist()} "
+                          f"last max {dbg[b, d, 2, lanes].view(np.float32).tolist()} k_end(all lanes) {dbg[b, d, 3].tolist()}")
+    return ws[o:o + 4 * B].view(torch.int32).cpu().numpy()
+
+
+def run(kind, B, T, U, V, seed=0, ragged=False, scale=1.0, ncheck=4, reps=20, tweak=None):
+    rng = np.random.default_rng(seed)
+    logits = (rng.standard_normal((B, T, V)) * scale).astype(np.float32)
+    labels = rng.integers(1, V, (B, U), dtype=np.int32)
+    if ragged:
+        tl = rng.integers(T // 2, T + 1, B).astype(np.int32); ll = rng.integers(U // 2, U + 1, B).astype(np.int32)
+    else:
+        tl = np.full(B, T, np.int32); ll = np.full(B, U, np.int32)
+    if tweak:
+        tweak(logits, labels, ll, tl)
+    k = ops.KINDS[kind]
+    p = ops.Prepared(torch.from_numpy(labels).to(dev), torch.from_numpy(logits).to(dev), torch.from_numpy(ll).to(dev),
+                     torch.from_numpy(tl).to(dev), 0, U=U)
+    ws = torch.zeros(_lib.workspace_bytes(_lib.WS_LOSS_GRAD, k, B, T, V, U), dtype=torch.uint8, device=dev)
+    name = _lib.pipeline_name(k, 0, B, T, V, U, True)
+    loss, grad = ops.loss_grad(k, _lib.WRT_LOGITS, p, True, workspace=ws)
+    torch.cuda.synchronize()
+    fl = flags_of(ws, k, B, T, V, U) if name == "fused6" else np.zeros(B, np.int32)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ops.loss_grad(k, _lib.WRT_LOGITS, p, True, workspace=ws)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    n = min(B, ncheck)
+    rl, rg = C.loss_grad(kind, labels[:n], logits[:n], ll[:n], tl[:n], 0)
+    ln, gn = loss.cpu().numpy(), grad.cpu().numpy()
+    fin = np.isfinite(rl)
+    okfin = np.array_equal(np.isfinite(ln[:n]), fin)
+    lerr = (np.abs(ln[:n][fin] - rl[fin]) / np.maximum(1, np.abs(rl[fin]))).max() if fin.any() else 0.0
+    gerr = np.abs(gn[:n] - rg).max()
+    if gerr > 1e-3:
+        e = np.abs(gn[:n] - rg)
+        bad = np.argwhere(e.max(axis=2) > 1e-3)
+        print("   bad frames of b=0:", [int(t) for bb, t in bad if bb == 0], "tl", tl[:n].tolist(), "ll", ll[:n].tolist())
+        b0, t0 = bad[0]
+        ks = np.argsort(-e[b0, t0])[:6]
+        print("   worst tokens at first bad frame:", [(int(k), float(gn[b0, t0, k]), float(rg[b0, t0, k])) for k in ks], "labels", labels[b0][:8].tolist())
+    if np.isnan(gn).any():
+        bad = np.argwhere(np.isnan(gn).any(axis=2))
+        print("   NaN frames (b, t):", bad[:24].tolist(), "tl", tl[:4].tolist())
+    print(f"{name:7s} {kind:10s} B={B:4d} T={T:5d} U={U:4d} V={V:5d} {'ragged' if ragged else 'full  '} scale={scale:g}: "
+          f"finite-match={okfin} loss rel {lerr:.2e} grad {gerr:.2e} nan={int(np.isnan(gn).sum())} flagged={int((fl != 0).sum())}/{B} "
+          f"(bits {hex(int(np.bitwise_or.reduce(fl))) if B else 0}) {dt * 1e3:.3f} ms", flush=True)
+    return lerr, gerr
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "small"):
+        for kind in ("classic", "simplified"):
+            run(kind, 4, 40, 6, 256, ragged=True)
+            run(kind, 6, 70, 20, 256, ragged=True)
+            run(kind, 6, 150, 100, 256, ragged=True)
+            run(kind, 6, 97, 40, 512, ragged=True)
+            run(kind, 6, 40, 12, 1024, ragged=True)
+            run(kind, 6, 260, 200, 256, ragged=True)
+            run(kind, 5, 33, 7, 29, ragged=True)
+            run(kind, 3, 300, 64, 64, ragged=False)
+    if which == "simp":
+        run("simplified", 2, 150, 100, 256, ragged=False)
+        run("simplified", 2, 48, 100, 256, ragged=False)
+        run("simplified", 2, 150, 65, 256, ragged=False)
+    if which == "seeds":
+        for sd in range(8):
+            run("classic", 256, 1000, 128, 256, seed=sd, ncheck=2, reps=10)
+    if which == "b128":
+        run("classic", 128, 1000, 128, 256, seed=2, ncheck=2, reps=50)
+        run("classic", 192, 1000, 128, 256, seed=2, ncheck=2, reps=50)
+        run("classic", 256, 1000, 128, 256, seed=2, ncheck=2, reps=50)
+    if which == "nsc":
+        run("classic", 256, 1000, 128, 256, seed=int(os.environ.get("F6_SEED", "2")), ncheck=2, reps=50)
+    if which == "ns":
+        run("classic", 256, 1000, 128, 256, ncheck=8)
+        run("simplified", 256, 1000, 128, 256, ncheck=8)
+    if which in ("all", "big"):
+        for kind in ("classic", "simplified"):
+            run(kind, 256, 1000, 128, 256, ncheck=8)
+            run(kind, 256, 1000, 128, 256, ragged=True, seed=1, ncheck=8)
+            run(kind, 256, 1000, 128, 256, scale=3.0, ncheck=4)
+            run(kind, 256, 1000, 128, 256, scale=10.0, ncheck=4)
+        run("classic", 64, 5000, 128, 256, ncheck=2, reps=5)
+        run("classic", 256, 500, 256, 256, ncheck=4)
+        run("classic", 256, 500, 60, 512, ncheck=4)
+        run("classic", 256, 300, 100, 1024, ncheck=4)
+        run("classic", 512, 1000, 128, 256, ragged=True, ncheck=4)

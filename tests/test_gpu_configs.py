@@ -37,10 +37,17 @@ def _inputs(B, T, U, V, seed):
 
 @pytest.mark.parametrize("kind", ["classic", "simplified"])
 @pytest.mark.parametrize("kernel", ["pair", "slab"])
-def test_config5_full_batch_hessian(kind, kernel, monkeypatch):
+def test_config5_full_batch_hessian(kind, kernel):
     from tf_seq2seq_losses_amd import ops, _lib
-    if kernel == "slab":
-        monkeypatch.setenv("CTC_AMD_HESSIAN", "slab")
+    _lib.debug_override("hessian", "slab" if kernel == "slab" else "")
+    try:
+        _config5_body(kind)
+    finally:
+        _lib.debug_override("hessian", "")
+
+
+def _config5_body(kind):
+    from tf_seq2seq_losses_amd import ops, _lib
     B, T, U, V = 32, 200, 32, 64
     logits, labels, ll, tl = _inputs(B, T, U, V, 0)
     tl[5], tl[30] = 150, 97          # two shorter utterances: rows and columns past the end must be zero

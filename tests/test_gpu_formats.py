@@ -111,7 +111,7 @@ def test_north_star_shape_bf16_time_major():
     assert torch.equal(l0, l1)
     assert torch.equal(g1, g0.to(torch.bfloat16))
     from tf_seq2seq_losses_amd import _lib
-    assert _lib.pipeline_name(0, 0, B, T, V, U, True) == "fused5"
+    assert _lib.pipeline_name(0, 0, B, T, V, U, True) == "fused6"
 
 
 @pytest.mark.parametrize("kind", ["classic", "simplified"])

@@ -1,5 +1,5 @@
-"""The fused loss+gradient kernels (csrc/ctc_fused5.hip, csrc/ctc_fused4.hip, csrc/ctc_fused.hip; V in {256, 512, 1024}, logits input) against the float64
-C oracle and against the three-kernel pipeline (CTC_AMD_PIPELINE=v1), including the edge cases the reference tests:
+"""The fused loss+gradient kernels (csrc/ctc_fused6.hip = the default tier "", csrc/ctc_fused5.hip, csrc/ctc_fused.hip; logits input) against
+the float64 C oracle and against the three-kernel pipeline (ctc_amd_debug_override("pipeline", "v1")), including the edge cases the reference tests:
 ragged and zero lengths, infeasible samples, empty labels, repeated tokens, d_loss weighting."""
 import os
 
@@ -16,8 +16,7 @@ TOL = 1e-4
 def _run(kind, logits, labels, ll, tl, pipeline, d_loss=None):
     from tf_seq2seq_losses_amd import ops, _lib
     dev = torch.device("cuda:0")
-    old = os.environ.get("CTC_AMD_PIPELINE")
-    os.environ["CTC_AMD_PIPELINE"] = pipeline
+    _lib.debug_override("pipeline", pipeline)
     try:
         p = ops.Prepared(torch.from_numpy(labels).to(dev), torch.from_numpy(logits).to(dev), torch.from_numpy(ll).to(dev),
                          torch.from_numpy(tl).to(dev), 0)
@@ -25,23 +24,20 @@ def _run(kind, logits, labels, ll, tl, pipeline, d_loss=None):
         loss, grad = ops.loss_grad(ops.KINDS[kind], _lib.WRT_LOGITS, p, True, d_loss=dl)
         torch.cuda.synchronize()
     finally:
-        if old is None:
-            del os.environ["CTC_AMD_PIPELINE"]
-        else:
-            os.environ["CTC_AMD_PIPELINE"] = old
+        _lib.debug_override("pipeline", "")
     return loss.cpu().numpy(), grad.cpu().numpy()
 
 
 def _check(kind, logits, labels, ll, tl, d_loss=None):
     l5, g5 = _run(kind, logits, labels, ll, tl, "fused5", d_loss)
-    lf, gf = _run(kind, logits, labels, ll, tl, "fused4", d_loss)
+    lf, gf = _run(kind, logits, labels, ll, tl, "", d_loss)  # default tier: fused6 (+ fused5 for what it flags)
     l2, g2 = _run(kind, logits, labels, ll, tl, "fused2", d_loss)
     l1, g1 = _run(kind, logits, labels, ll, tl, "v1", d_loss)
     rl, rg = C.loss_grad(kind, labels, logits, ll, tl, 0)
     if d_loss is not None:
         rg = rg * d_loss[:, None, None]
     fin = np.isfinite(rl)
-    for lo, gr, name in ((l5, g5, "fused5"), (lf, gf, "fused4"), (l2, g2, "fused2"), (l1, g1, "v1")):
+    for lo, gr, name in ((l5, g5, "fused5"), (lf, gf, "fused6"), (l2, g2, "fused2"), (l1, g1, "v1")):
         assert np.array_equal(np.isfinite(lo), fin), name
         assert np.all(lo[~fin] == np.inf), name
         if fin.any():
@@ -79,7 +75,7 @@ def test_fused_edge_lengths(kind):
     rl, rg = C.loss_grad(kind, labels, logits, ll, tl_ref, 0)
     rg = rg * d_loss[:, None, None]
     fin = np.isfinite(rl)
-    for pipeline in ("fused5", "fused4", "fused2"):
+    for pipeline in ("", "fused5", "fused2"):
         lf, gf = _run(kind, logits, labels, ll, tl, pipeline, d_loss)
         assert np.array_equal(np.isfinite(lf), fin), pipeline
         assert (np.abs(lf[fin] - rl[fin]) / np.maximum(1, np.abs(rl[fin]))).max() < TOL, pipeline
@@ -115,7 +111,7 @@ def test_loss_only_stops_at_the_meeting_point(kind):
     dev = torch.device("cuda:0")
     p = ops.Prepared(torch.from_numpy(labels).to(dev), torch.from_numpy(logits).to(dev), torch.from_numpy(ll).to(dev),
                      torch.from_numpy(tl).to(dev), 0)
-    assert _lib.pipeline_name(ops.KINDS[kind], _lib.WRT_LOGITS, B, T, V, U, False) == "fused5"
+    assert _lib.pipeline_name(ops.KINDS[kind], _lib.WRT_LOGITS, B, T, V, U, False) == "fused6"
     l_only, g_none = ops.loss_grad(ops.KINDS[kind], _lib.WRT_LOGITS, p, False)
     l_both, _ = ops.loss_grad(ops.KINDS[kind], _lib.WRT_LOGITS, p, True)
     assert g_none is None

@@ -127,7 +127,7 @@ def test_hvp_nonzero_blank_and_symmetry(kind):
 
 @pytest.mark.parametrize("kind", ["classic", "simplified"])
 def test_autograd_second_order_uses_hvp(kind, monkeypatch):
-    """README.md:58-71 route: grad of <gradient, v>; the materialised route (CTC_AMD_HVP=dense) must agree."""
+    """README.md:58-71 route: grad of <gradient, v>; the materialised route (losses.HVP_DENSE) must agree."""
     import tf_seq2seq_losses_amd as ctc
     inp = O.generate_ctc_loss_inputs(4, 24, 7, 6)
     fn = ctc.classic_ctc_loss if kind == "classic" else ctc.simplified_ctc_loss
@@ -143,7 +143,8 @@ def test_autograd_second_order_uses_hvp(kind, monkeypatch):
 
     wts = _t(np.array([1.0, 2.0, -0.5, 3.0], np.float32))
     fast = second(wts)
-    monkeypatch.setenv("CTC_AMD_HVP", "dense")
+    from tf_seq2seq_losses_amd import losses
+    monkeypatch.setattr(losses, "HVP_DENSE", True)
     dense = second(wts)
     assert torch.isfinite(fast).all()
     assert ((fast - dense).abs().max() / max(1.0, dense.abs().max().item())).item() < TOL

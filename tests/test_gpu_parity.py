@@ -127,10 +127,14 @@ def test_random_reference_sizes(kind, B, T, V, seed):
 @pytest.mark.parametrize("kind", ["classic", "simplified"])
 @pytest.mark.parametrize("B,T,V,seed", [(8, 20, 8, 0), (5, 33, 7, 4)])
 def test_hessian_one_slab_per_wavefront_kernel(kind, B, T, V, seed, monkeypatch):
-    """Labels of at most 32 positions take the two-slabs-per-wavefront Hessian kernel; CTC_AMD_HESSIAN=slab forces the
+    """Labels of at most 32 positions take the two-slabs-per-wavefront Hessian kernel; ctc_amd_debug_override("hessian", "slab") forces the
     general one (used for longer labels), which must give the same numbers."""
-    monkeypatch.setenv("CTC_AMD_HESSIAN", "slab")
-    _compare(kind, O.generate_ctc_loss_inputs(B, T, seed, V), ab=False)
+    from tf_seq2seq_losses_amd import _lib
+    _lib.debug_override("hessian", "slab")
+    try:
+        _compare(kind, O.generate_ctc_loss_inputs(B, T, seed, V), ab=False)
+    finally:
+        _lib.debug_override("hessian", "")
 
 
 @pytest.mark.parametrize("kind", ["classic", "simplified"])

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTC_AMD_LIB", os.path.join(_HERE, "libctc_amd.so"))  # override: kernel experiments only
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 CLASSIC, SIMPLIFIED = 0, 1
 WRT_LOGITS, WRT_LOGPROBS = 0, 1
 WS_LOSS_GRAD, WS_ALPHA_BETA, WS_HESSIAN, WS_HVP = 0, 1, 2, 3
@@ -31,6 +31,7 @@ SIGNATURES = {
     "ctc_amd_abi_version": (_c_int, []),
     "ctc_amd_last_error": (ctypes.c_char_p, []),
     "ctc_amd_pipeline_name": (ctypes.c_char_p, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
+    "ctc_amd_debug_override": (_c_int, [ctypes.c_char_p, ctypes.c_char_p]),
     "ctc_amd_workspace_bytes": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_size_t)]),
     "ctc_amd_loss_grad": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "ctc_amd_loss_grad_ex": (_c_int, [_c_int, _c_int, _c_void_p, _c_int, ctypes.c_int64, ctypes.c_int64,  # kind, wrt, logits, dtype, strides
@@ -83,6 +84,12 @@ def check(rc: int, what: str) -> None:
 
 def pipeline_name(kind: int, wrt: int, B: int, T: int, V: int, U: int, want_grad: bool = True) -> str:
     return load().ctc_amd_pipeline_name(kind, wrt, B, T, V, U, int(want_grad)).decode()
+
+
+def debug_override(key: str, value: str = "") -> None:
+    """Diagnostic (parity tests, benchmarks): force a lower kernel tier ("pipeline": "v1" | "fused2" | "fused5") or the
+    general Hessian kernel ("hessian": "slab"); the empty string restores the default.  Process-wide."""
+    check(load().ctc_amd_debug_override(key.encode(), value.encode()), "ctc_amd_debug_override")
 
 
 def workspace_bytes(what: int, kind: int, B: int, T: int, V: int, U: int) -> int:

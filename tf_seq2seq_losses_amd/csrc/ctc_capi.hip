@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "ctc_amd.h"
 #include "ctc_common.h"
@@ -12,10 +13,14 @@ hipError_t run_grad(const Problem &p, const Layout &L, char *ws, const float *d_
 hipError_t run_convert(const Problem &p, const Layout &L, char *ws, float *alpha_out, float *beta_out, hipStream_t st);
 hipError_t run_fused_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 hipError_t run_fused_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
-#define CTC_F5_DECL(name) hipError_t name(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st)
+#define CTC_F5_DECL(name) hipError_t name(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, bool only_flagged, hipStream_t st)
 CTC_F5_DECL(run_fused5_classic_nl1); CTC_F5_DECL(run_fused5_classic_nl2); CTC_F5_DECL(run_fused5_classic_nl4);
 CTC_F5_DECL(run_fused5_simplified_nl1); CTC_F5_DECL(run_fused5_simplified_nl2); CTC_F5_DECL(run_fused5_simplified_nl4);
 #undef CTC_F5_DECL
+#define CTC_F6_DECL(name) hipError_t name(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st)
+CTC_F6_DECL(run_fused6_classic_nl1); CTC_F6_DECL(run_fused6_classic_nl2); CTC_F6_DECL(run_fused6_classic_nl4);
+CTC_F6_DECL(run_fused6_simplified_nl1); CTC_F6_DECL(run_fused6_simplified_nl2); CTC_F6_DECL(run_fused6_simplified_nl4);
+#undef CTC_F6_DECL
 // shapes the checkpoint + recompute kernel (ctc_fused5.hip) is instantiated for: logits input, V <= 512 (smaller
 // vocabularies run with the lanes beyond V masked; V or strides not a multiple of 4: element-wise row accesses), U <= 256
 inline bool plain_format(const Problem &p) {  // contiguous float32 [B,T,V] logits and gradient
@@ -27,22 +32,26 @@ inline bool fused5_eligible(const Problem &p, const Layout &L) {
   return p.wrt == 0 && (p.V <= 512 || (p.V <= 1024 && L.NL <= 2)) && L.NL <= 4 && p.B > 0 && p.T > 0 && p.xdtype == p.gdtype &&
          (p.xdtype == 0 || ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0);
 }
-inline hipError_t run_fused5(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
+inline hipError_t run_fused5(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, bool only_flagged, hipStream_t st) {
   switch (L.NL) {  // one translation unit of ctc_fused5.hip per (kind, label positions per lane)
-    case 1: return p.kind == 0 ? run_fused5_classic_nl1(p, L, ws, loss, d_loss, grad, st) : run_fused5_simplified_nl1(p, L, ws, loss, d_loss, grad, st);
-    case 2: return p.kind == 0 ? run_fused5_classic_nl2(p, L, ws, loss, d_loss, grad, st) : run_fused5_simplified_nl2(p, L, ws, loss, d_loss, grad, st);
-    case 4: return p.kind == 0 ? run_fused5_classic_nl4(p, L, ws, loss, d_loss, grad, st) : run_fused5_simplified_nl4(p, L, ws, loss, d_loss, grad, st);
+    case 1: return p.kind == 0 ? run_fused5_classic_nl1(p, L, ws, loss, d_loss, grad, only_flagged, st) : run_fused5_simplified_nl1(p, L, ws, loss, d_loss, grad, only_flagged, st);
+    case 2: return p.kind == 0 ? run_fused5_classic_nl2(p, L, ws, loss, d_loss, grad, only_flagged, st) : run_fused5_simplified_nl2(p, L, ws, loss, d_loss, grad, only_flagged, st);
+    case 4: return p.kind == 0 ? run_fused5_classic_nl4(p, L, ws, loss, d_loss, grad, only_flagged, st) : run_fused5_simplified_nl4(p, L, ws, loss, d_loss, grad, only_flagged, st);
     default: return hipErrorInvalidValue;
   }
 }
-hipError_t run_fused4_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
-hipError_t run_fused4_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
-// shapes the chain + helper kernel (ctc_fused4.hip) is instantiated for: logits input, V = 256, U <= 128 (LDS budget)
-inline bool fused4_eligible(const Problem &p, const Layout &L) {
-  return p.wrt == 0 && p.V == 256 && L.NL <= 2 && p.B > 0 && p.T > 0 && plain_format(p);
-}
-inline hipError_t run_fused4(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
-  return p.kind == 0 ? run_fused4_classic(p, L, ws, loss, d_loss, grad, st) : run_fused4_simplified(p, L, ws, loss, d_loss, grad, st);
+// The linear-domain kernel (ctc_fused6.hip) covers the shapes of fused5 and is followed by a fused5 launch restricted to the
+// utterances it flagged (dynamic range beyond float32 mantissas with per-lane exponents; normally none).
+inline hipError_t run_fused6(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
+  hipError_t e;
+  switch (L.NL) {
+    case 1: e = p.kind == 0 ? run_fused6_classic_nl1(p, L, ws, loss, d_loss, grad, st) : run_fused6_simplified_nl1(p, L, ws, loss, d_loss, grad, st); break;
+    case 2: e = p.kind == 0 ? run_fused6_classic_nl2(p, L, ws, loss, d_loss, grad, st) : run_fused6_simplified_nl2(p, L, ws, loss, d_loss, grad, st); break;
+    case 4: e = p.kind == 0 ? run_fused6_classic_nl4(p, L, ws, loss, d_loss, grad, st) : run_fused6_simplified_nl4(p, L, ws, loss, d_loss, grad, st); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  return run_fused5(p, L, ws, loss, d_loss, grad, true, st);
 }
 // shapes the two-wavefront fused kernel (ctc_fused.hip) is instantiated for: logits input, V in {256, 512, 1024}, U <= 256
 inline bool fused_eligible(const Problem &p, const Layout &L) {
@@ -54,6 +63,9 @@ inline hipError_t run_fused(const Problem &p, const Layout &L, char *ws, float *
 size_t hessian_extra_bytes(int kind, int B, int T, int V, int U);
 hipError_t run_hessian(const Problem &p, const Layout &L, char *ws, const float *grad, float *hess, hipStream_t st);
 size_t hvp_extra_bytes(int kind, int B, int T, int V, int U);
+// diagnostic overrides (ctc_amd_debug_override): process-wide, written only by tests / benchmarks between calls
+int g_force_pipeline = 0;      // 0 = best eligible tier, 1 = v1, 2 = fused2, 5 = fused5 (log domain)
+int g_force_hessian_slab = 0;  // 1 = the general one-slab-per-wavefront Hessian kernel also for short labels
 hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec, float *out, hipStream_t st);
 }  // namespace ctc
 
@@ -106,21 +118,34 @@ int ctc_amd_abi_version(void) { return CTC_AMD_ABI_VERSION; }
 const char *ctc_amd_last_error(void) { return g_err; }
 
 static const char *select_pipeline(const ctc::Problem &p, const ctc::Layout &L, bool want_grad) {
-  // pipeline selection by shape eligibility: fused5 (ctc_fused5.hip: chains + recompute chains + helpers, no lattice
-  // spill) > fused4 (ctc_fused4.hip: chains + helpers, half of the lattice spilled) > fused2 (ctc_fused.hip: two
-  // self-contained wavefronts) > v1 (emit -> scan -> grad).  CTC_AMD_PIPELINE=v1|fused2|fused4 forces a lower tier
-  // (the parity tests run all of them).
-  const char *pipe = getenv("CTC_AMD_PIPELINE");
-  const bool force_v1 = pipe && pipe[0] == 'v' && pipe[1] == '1';
-  const bool force_f2 = pipe && pipe[0] == 'f' && pipe[5] == '2';
-  const bool force_f4 = pipe && pipe[0] == 'f' && pipe[5] == '4';
-  if (force_v1) return "v1";
-  // loss only (grad == NULL): fused5 stops at the meeting point of its two chains; the other fused tiers need a gradient
-  if (!force_f2 && !force_f4 && ctc::fused5_eligible(p, L)) return "fused5";
+  // pipeline selection by shape eligibility: fused6 (ctc_fused6.hip: linear-domain chains + recompute chains + helpers,
+  // followed by a fused5 launch for the utterances it flags) = fused5 (ctc_fused5.hip: the same decomposition in the log
+  // domain) > fused2 (ctc_fused.hip: two self-contained wavefronts) > v1 (emit -> scan -> grad).  A lower tier can be
+  // forced through ctc_amd_debug_override (the parity tests run all of them); nothing here reads the environment.
+  const int forced = ctc::g_force_pipeline;
+  if (forced == 1) return "v1";
+  // loss only (grad == NULL): fused5 / fused6 stop at the meeting point of their two chains; fused2 needs a gradient
+  if (forced == 0 && ctc::fused5_eligible(p, L)) return "fused6";
+  if (forced == 5 && ctc::fused5_eligible(p, L)) return "fused5";
   if (!want_grad) return "v1";
-  if (!force_f2 && ctc::fused4_eligible(p, L)) return "fused4";
   if (ctc::fused_eligible(p, L)) return "fused2";
   return "v1";
+}
+
+int ctc_amd_debug_override(const char *key, const char *value) {
+  if (!key || !value) return fail(CTC_AMD_EINVAL, "null key/value");
+  if (!strcmp(key, "pipeline")) {
+    const int f = !strcmp(value, "") ? 0 : !strcmp(value, "v1") ? 1 : !strcmp(value, "fused2") ? 2 : !strcmp(value, "fused5") ? 5 : -1;
+    if (f < 0) return fail(CTC_AMD_EINVAL, "pipeline override must be \"\", \"v1\", \"fused2\" or \"fused5\", got \"%s\"", value);
+    ctc::g_force_pipeline = f;
+    return CTC_AMD_OK;
+  }
+  if (!strcmp(key, "hessian")) {
+    if (strcmp(value, "") && strcmp(value, "slab")) return fail(CTC_AMD_EINVAL, "hessian override must be \"\" or \"slab\", got \"%s\"", value);
+    ctc::g_force_hessian_slab = !strcmp(value, "slab");
+    return CTC_AMD_OK;
+  }
+  return fail(CTC_AMD_EINVAL, "unknown override key \"%s\"", key);
 }
 
 const char *ctc_amd_pipeline_name(int kind, int wrt, int B, int T, int V, int U, int want_grad) {
@@ -153,8 +178,8 @@ static int loss_grad_impl(ctc::Problem p, float *loss, void *grad, const float *
   const char *pl = select_pipeline(p, L, grad != nullptr);
   if (pl[0] == 'f') {
     char *wsb = static_cast<char *>(workspace);
-    hipError_t ef = (pl[5] == '5') ? ctc::run_fused5(p, L, wsb, loss, d_loss, gradf, st)
-                  : (pl[5] == '4') ? ctc::run_fused4(p, L, wsb, loss, d_loss, gradf, st)
+    hipError_t ef = (pl[5] == '6') ? ctc::run_fused6(p, L, wsb, loss, d_loss, gradf, st)
+                  : (pl[5] == '5') ? ctc::run_fused5(p, L, wsb, loss, d_loss, gradf, false, st)
                                    : ctc::run_fused(p, L, wsb, loss, d_loss, gradf, st);
     if (ef != hipSuccess) return hip_fail(ef, pl);
     return CTC_AMD_OK;

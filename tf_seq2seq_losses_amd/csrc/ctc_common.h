@@ -90,7 +90,7 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
 //   logp  [B] double       : log2 P(label | logits), -inf when infeasible
 struct Layout {
   int NL, UP, ERS, SRS;
-  size_t off_emis, off_alpha, off_beta, off_logp, off_dummy, off_perm, off_extra, total;
+  size_t off_emis, off_alpha, off_beta, off_logp, off_dummy, off_perm, off_kexp, off_flags, off_extra, total;
 };
 
 inline int nl_for(int U) {
@@ -113,6 +113,10 @@ inline Layout make_layout(int kind, int B, int T, int U, size_t extra_bytes) {
   L.off_logp = o;  o = al(o + (size_t)B * 8);
   L.off_dummy = o; o = al(o + (size_t)B * 2 * 1024);  // (also: 16 B per wavefront of diagnostic stamps)  // per-wavefront sink for the pacing stores of the fused kernel
   L.off_perm = o;  o = al(o + (size_t)B * 4);  // longest-first order of the utterances (fused kernel, B > number of CUs)
+  // linear-domain fused kernel (ctc_fused6.hip): per-lane exponents of its checkpoint rows ([B][2][T/6 + 3][64] int32) and the
+  // per-utterance flags that send an utterance to the log-domain kernel
+  L.off_kexp = o;  o = al(o + (size_t)B * 2 * ((T + 5) / 6 + 3) * 64 * 4);
+  L.off_flags = o; o = al(o + (size_t)B * 4 + (size_t)B * 2048 * 4);  // (+ 8 KB per utterance for diagnostic builds)
   L.off_extra = o; o = al(o + extra_bytes);
   L.total = o;
   return L;

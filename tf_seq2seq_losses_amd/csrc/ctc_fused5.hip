@@ -807,12 +807,15 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused5_kernel(Problem p, La
                                                                     float *__restrict__ loss,
                                                                     const float *__restrict__ d_loss,
                                                                     float *__restrict__ grad, void *stamp_ws,
-                                                                    const int *__restrict__ perm) {
+                                                                    const int *__restrict__ perm,
+                                                                    const int *__restrict__ only_if) {
   __shared__ __attribute__((aligned(16))) Lds<KIND, NL, NH, BLK, VPL> lds;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps everything derived from it in SGPRs
   // utterance of this workgroup: workgroups start in index order, and with more utterances than CUs the longest ones
   // go first (perm from order_kernel; ragged batch of 512: -22 %)
   const int b = perm ? perm[blockIdx.x] : (int)blockIdx.x;
+  // fallback launch behind the linear-domain kernel (ctc_fused6.hip): only the utterances it flagged
+  if (only_if && only_if[b] == 0) return;
   Geo<BLK> geo;  // every wavefront derives the same block schedule: the barrier counts match by construction
   geo.init(clampi(p.logit_length[b], 0, p.T));
   if (w == 0) {
@@ -836,42 +839,26 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused5_kernel(Problem p, La
 
 }  // namespace fused5
 
-// perm[rank] = utterance with the rank-th longest logit_length (ties by index): B <= 8192, one thread per utterance; the
-// lengths are staged in LDS once per workgroup (a per-thread loop over global memory took ~30 us at B = 512)
-static __global__ __launch_bounds__(256) void order_kernel(const int *__restrict__ logit_length, int B, int T,
-                                                           int *__restrict__ perm) {
-  __shared__ int len_s[8192];
-  for (int j = threadIdx.x; j < B; j += 256) len_s[j] = fused::clampi(logit_length[j], 0, T);
-  __syncthreads();
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= B) return;
-  const int mine = len_s[b];
-  int rank = 0;
-  for (int j = 0; j < B; ++j) {
-    const int other = len_s[j];
-    rank += (other > mine) || (other == mine && j < b);
-  }
-  perm[rank] = b;
-}
+hipError_t run_order(const Problem &p, const Layout &L, char *ws, hipStream_t st);  // ctc_kernels.hip: longest utterances first
 
 template <int NL, int NH, int BLK, int VPL>
 static hipError_t launch5(const Problem &p, const Layout &L, float *a, float *b, double *lp, float2 *stats, float *loss,
-                          const float *d_loss, float *grad, void *stamp, const int *perm, hipStream_t st) {
+                          const float *d_loss, float *grad, void *stamp, const int *perm, const int *only_if, hipStream_t st) {
   static_assert(sizeof(fused5::Lds<CTC_FUSED_KIND, NL, NH, BLK, VPL>) <= 160 * 1024, "LDS budget of one CU");
   const bool plain = p.xdtype == 0 && p.V == 256 * VPL && p.xst == p.V && p.gst == p.V;  // frame stride folded into the addressing
   const dim3 grid(p.B), block(64 * (4 + 2 * NH));
   if (plain)
     hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 0>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
-                       d_loss, grad, stamp, perm);
+                       d_loss, grad, stamp, perm, only_if);
   else if (p.xdtype == 0 && ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0)
     hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 1>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
-                       d_loss, grad, stamp, perm);
+                       d_loss, grad, stamp, perm, only_if);
   else if (p.xdtype == 0)  // vocabulary or strides not a multiple of 4 elements: element-wise row accesses
     hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 3>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
-                       d_loss, grad, stamp, perm);
+                       d_loss, grad, stamp, perm, only_if);
   else
     hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 2>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
-                       d_loss, grad, stamp, perm);
+                       d_loss, grad, stamp, perm, only_if);
   return hipGetLastError();
 }
 
@@ -888,7 +875,7 @@ static hipError_t launch5(const Problem &p, const Layout &L, float *a, float *b,
 #define CTC_F5_ENTRY CTC_F5_CAT(run_fused5_simplified, _nl, CTC_FUSED5_NL)
 #endif
 hipError_t CTC_F5_ENTRY(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad,
-                        hipStream_t st) {
+                        bool only_flagged, hipStream_t st) {
   float *alpha = reinterpret_cast<float *>(ws + L.off_alpha);
   float *beta = reinterpret_cast<float *>(ws + L.off_beta);
   double *logp = reinterpret_cast<double *>(ws + L.off_logp);
@@ -897,12 +884,13 @@ hipError_t CTC_F5_ENTRY(const Problem &p, const Layout &L, char *ws, float *loss
   if (L.NL != CTC_FUSED5_NL) return hipErrorInvalidValue;
   // more utterances than CUs: longest first (one small kernel; skipped for batches that fit the chip in one go)
   int *perm = nullptr;
+  // behind ctc_fused6.hip: only the utterances whose flag it set (normally none: the workgroups leave at once)
+  const int *only_if = only_flagged ? reinterpret_cast<const int *>(ws + L.off_flags) : nullptr;
 #ifndef CTC_FUSED_STAMPS
-  if (p.B > 256 && p.B <= 8192) {
-    perm = reinterpret_cast<int *>(ws + L.off_perm);
-    hipLaunchKernelGGL(order_kernel, dim3((p.B + 255) / 256), dim3(256), 0, st, p.logit_length, p.B, p.T, perm);
-    hipError_t e = hipGetLastError();
+  if (!only_flagged && p.B > 256 && p.B <= 8192) {
+    hipError_t e = run_order(p, L, ws, st);
     if (e != hipSuccess) return e;
+    perm = reinterpret_cast<int *>(ws + L.off_perm);
   }
 #endif
   // Vocabularies of 257 .. 512 tokens: two 16-byte segments of the logits row per lane (VPL = 2); the five-block ring of
@@ -910,12 +898,12 @@ hipError_t CTC_F5_ENTRY(const Problem &p, const Layout &L, char *ws, float *loss
   // 129 .. 256 label positions (four per lane): the LDS rows are twice as long -- the 8-wavefront configuration as well.
   // 513 .. 1024 tokens: four segments per lane; the G stage re-reads its logits rows (no room for the five-block ring).
 #if CTC_FUSED5_NL == 4
-  return p.V <= 256 ? launch5<4, 2, 6, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, perm, st)
-                    : launch5<4, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, perm, st);
+  return p.V <= 256 ? launch5<4, 2, 6, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, perm, only_if, st)
+                    : launch5<4, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, perm, only_if, st);
 #else
-  return p.V <= 256   ? launch5<CTC_FUSED5_NL, 4, 12, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, perm, st)
-         : p.V <= 512 ? launch5<CTC_FUSED5_NL, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, perm, st)
-                      : launch5<CTC_FUSED5_NL, 2, 6, 4>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, perm, st);
+  return p.V <= 256   ? launch5<CTC_FUSED5_NL, 4, 12, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, perm, only_if, st)
+         : p.V <= 512 ? launch5<CTC_FUSED5_NL, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, perm, only_if, st)
+                      : launch5<CTC_FUSED5_NL, 2, 6, 4>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, perm, only_if, st);
 #endif
 }
 

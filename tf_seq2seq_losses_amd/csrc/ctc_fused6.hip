@@ -1,0 +1,1393 @@
+// Fused loss + gradient kernel for gfx950, pipeline v6: the lattice recursion in the LINEAR domain.
+//
+// Same decomposition as ctc_fused5.hip (one workgroup of 4 + 2*NH wavefronts per utterance: two main chains that meet in
+// the middle, two recompute chains, NH helpers a side, one checkpoint row per block in HBM, everything else in LDS, ONE
+// raw s_barrier per block), but alpha / beta are carried as float32 MANTISSAS with ONE INTEGER EXPONENT PER LANE (block
+// floating point over the NL label positions of a lane) instead of base-2 logarithms:
+//
+//   * a lattice step is 2 adds + 2 multiplies per label position instead of two log-sum-exp (4 transcendentals): the
+//     chains issue ~3x fewer instructions, and the whole kernel moves from VALU-issue-bound to memory-bound;
+//   * every operation carries a RELATIVE error of 2^-24 instead of an absolute error of 2^-24 * |log value|: at T = 1000
+//     the gradient agrees with a float64 evaluation to ~1e-6 (log-domain float32: 2.6e-4 here, 3e-3 for a scalar port);
+//   * emissions are exp(x - rowmax), NOT normalised: log2 sum_k exp(x_k - rowmax) of every frame is accumulated in
+//     double by the worker that first touches the frame and enters the loss only; posteriors are scale free;
+//   * a row of the lattice spans hundreds of binary orders of magnitude even for N(0,1) logits (alpha peaks at the last
+//     label position while beta peaks at the first), which one exponent per ROW cannot hold in float32; one exponent per
+//     LANE does: neighbouring label positions differ by a few bits.  Every RN frames each lane renormalises to its own
+//     maximum (no cross-lane reduction) and re-aligns the one value it receives from its neighbour lane by the difference
+//     of the two exponents (one v_ldexp_f32 per step).
+//
+// The float32 mantissas flush below 2^-126.  Inputs whose dynamic range inside a lane exceeds what that leaves (logits
+// of +-1e10, -inf, hard zeros in the needed emissions -- README.md:74-78) are DETECTED, not approximated: the kernel
+// raises a per-utterance flag (conditions D1..D5 below) and the caller re-runs exactly those utterances through the
+// log-domain kernel of ctc_fused5.hip, which has no range limit.  For unflagged utterances the mass lost to flushing is
+// bounded by 2^-28 of P.
+//
+//   D1  P == 0, inf or NaN at the meeting point (includes structurally infeasible utterances)
+//   D2  an emission needed by the lattice (label token or blank inside label_length) below 2^-120 of the row maximum: an
+//       emission that flushes is lost by BOTH chains alike, the one loss the check D6 cannot see
+//   D6  (calls with a gradient) the posterior mass of a frame, sum over all lattice states of alpha beta / P, differs from
+//       1 by more than 1e-4.  Flushing only ever removes mass, and mass that one chain loses at (t1, s1) is still carried
+//       by the other chain on the far side of t1, so sum_s alpha_t beta_t stops being the same for all t: every frame is
+//       checked against P from the meeting point.  A loss below 1e-4 of P is below the tolerance of the gradient.
+//   D3-D5 (calls WITHOUT a gradient have no phase 2 to check the mass in; they fall back on conservative local signs)
+//       D3 a renormalisation scales a lane's own live values down by more than 2^-64; D4 a lane's maximum decays by more
+//       than 2^-64 within one renormalisation period, or a live lane goes to zero
+//
+// References: classic_ctc_loss.py:310-462,565-669, simplified_ctc_loss.py:291-438,456-534, base_loss.py:262-298,328-344,
+// 420-468, tools.py:27-40.
+#include "ctc_fused_common.h"
+
+#ifndef CTC_FUSED_KIND
+#error "compile with -DCTC_FUSED_KIND=0 (classic) or 1 (simplified)"
+#endif
+
+namespace ctc {
+namespace fused6 {
+
+using namespace ctc::fused;
+
+constexpr int DEAD = -(1 << 24);  // exponent of a lane whose mantissas are all zero
+constexpr int GAP = 16;           // a dead lane adopts its upstream neighbour's exponent minus GAP
+constexpr int DOWN_MAX = 64;      // D3
+constexpr int DECAY_MAX = 64;     // D4
+constexpr int KK_MAX = 80;        // posterior scale clamp: a lane's alpha and beta exponents above log2 P by more than this
+                                  // (their true product is <= P) means lost mass -- D6 sees it
+constexpr float EMIS_MIN = 7.52316384526264e-37f;  // 2^-120 (D2)
+
+#ifdef CTC_F6_STAMPS
+// diagnostic build: cycles of work / of waiting at the block barriers, per wavefront and phase (thread-private registers)
+struct Stamps {
+  unsigned long long work[2] = {0, 0}, wait[2] = {0, 0}, t0 = 0;
+  int ph = 0;
+};
+__device__ Stamps *g_stamps_dummy;
+#define F6_ST_ARG , st_
+#define F6_STAMP_DECL Stamps st_; st_.t0 = __builtin_amdgcn_s_memtime();
+#define F6_STAMP_PHASE2 st_.ph = 1;
+#define F6_BARRIER() do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_.work[st_.ph] += t_ - st_.t0; block_barrier_raw(); \
+    unsigned long long u_ = __builtin_amdgcn_s_memtime(); st_.wait[st_.ph] += u_ - t_; st_.t0 = u_; } while (0)
+#define F6_STAMP_DUMP(wave) do { if ((threadIdx.x & 63) == 0) { unsigned long long *q_ = reinterpret_cast<unsigned long long *>(flag_ws_dbg + p.B) + ((long)b * 16 + (wave)) * 4; \
+    q_[0] = st_.work[0]; q_[1] = st_.wait[0]; q_[2] = st_.work[1]; q_[3] = st_.wait[1]; } } while (0)
+#else
+#define F6_ST_ARG
+#define F6_STAMP_DECL
+#define F6_STAMP_PHASE2
+#define F6_BARRIER() block_barrier_raw()
+#define F6_STAMP_DUMP(wave)
+#endif
+__device__ __forceinline__ void block_barrier_raw() {
+#ifdef CTC_F6_SYNC
+  __syncthreads();
+#else
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed; vmcnt untouched
+  __builtin_amdgcn_s_barrier();
+#endif
+}
+
+__device__ __forceinline__ int from_prev_lane_i(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int from_next_lane_i(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ float ldexp_f(float x, int e) { return __builtin_ldexpf(x, e); }
+__device__ __forceinline__ int frexp_e(float x) { return __builtin_amdgcn_frexp_expf(x); }
+__device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+// renormalisation period inside a block and the number of lanes the lattice front can cross in one period
+template <int BLK, int NL>
+struct Cad {
+  static constexpr int RN = (BLK % 4 == 0) ? 4 : 3;
+  static constexpr int NG = BLK / RN;            // exponent groups of the rows of one block
+  // adoption levels: lanes the front crosses in one period, + 1 because the recompute chain shifts its row into the other
+  // direction's slot order right after a step, which reads the front one lane further than the next step would
+  static constexpr int LV = (RN + NL - 1) / NL + 1;
+  static_assert(BLK % RN == 0, "block length must be a multiple of the renormalisation period");
+};
+
+template <int KIND, int NL, int NH, int BLK, int VPL>
+struct Lds {
+  static constexpr int V = 256 * VPL, UP = 64 * NL;
+  static constexpr int ES = UP + 4;      // E row: y[UP] (exp(x_label - rowmax)), then e_blank
+  static constexpr int RS = 2 * UP + 8;  // R row (recompute chain): the other direction's mantissas in the main chain's slot order,
+                                         // tail (state outside the slot range, its exponent); S row (main chain, in place): per lane
+                                         // 2 NL floats (blank posterior of the lane, token posteriors) in units of 2^-30
+  static constexpr int NG = Cad<BLK, NL>::NG;
+  static constexpr int NW = 4 + 2 * NH;
+  float E[2][3][BLK][ES];   // [side][block % 3]
+  float R[2][3][BLK][RS];   // [side][block % 3]
+  int kg[2][3][NG][64];     // per-lane exponents of the R rows, one set per renormalisation group
+  float xcopy[2 * NH][V + 4];
+  float xcopy_r[2][V + 4];  // row copies of the recompute waves (E stage of phase 1)
+  float bins[2 * NH][V + 4];
+  float dump[NW][64];
+  double l2s[NW];           // per worker: sum over its phase-1 frames of log2 sum_k exp(x_k - rowmax)
+  int flag;                 // OR of D1..D5 over the wavefronts
+  int feasible;             // 1: phase 2 runs
+  int lp_int;               // posterior scale: 2^-lp_int * cf = 1 / (P in mantissa units)
+  float cf;
+};
+
+// Block geometry shared by every wavefront of the workgroup (identical to ctc_fused5.hip).
+template <int BLK>
+struct Geo {
+  int len, G, tmb, tm, NB;
+  __device__ __forceinline__ void init(int len_) {
+    len = len_;
+    G = (len + BLK - 1) / BLK;
+    tmb = G / 2;
+    tm = tmb * BLK;
+    NB = G - tmb;
+  }
+  __device__ __forceinline__ int nvof(int g) const { int r = len - BLK * g; return r < BLK ? r : BLK; }
+  __device__ __forceinline__ int nblocks(int phase, int side) const { return (phase == 1) == (side == 0) ? tmb : G - tmb; }
+  __device__ __forceinline__ int absblock(int phase, int side, int j) const {
+    if (phase == 1) return side == 0 ? j : G - 1 - j;
+    return side == 0 ? tmb + j : tmb - 1 - j;
+  }
+  __device__ __forceinline__ int frame(int side, int g, int d) const { return side == 0 ? BLK * g + d : BLK * g + nvof(g) - 1 - d; }
+  // checkpoint slot of lattice time t (multiples of BLK, and `len`): distinct per direction
+  __device__ __forceinline__ int slot(int t) const { return (t + BLK - 1) / BLK; }
+};
+
+// NL consecutive floats (or pairs) of this lane in an LDS / HBM row
+template <int NL>
+__device__ __forceinline__ void ld_slots(const float *p, float (&v)[NL]) {
+  if constexpr (NL == 1) v[0] = p[0];
+  else if constexpr (NL == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y; }
+  else {
+#pragma unroll
+    for (int q = 0; q < NL / 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4 *>(p + 4 * q);
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+  }
+}
+template <int NL>
+__device__ __forceinline__ void st_slots(float *p, const float (&v)[NL]) {
+  if constexpr (NL == 1) p[0] = v[0];
+  else if constexpr (NL == 2) *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+  else {
+#pragma unroll
+    for (int q = 0; q < NL / 4; ++q) *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  }
+}
+template <int NL>
+__device__ __forceinline__ void ld_pairs(const float *p, float (&a)[NL], float (&b)[NL]) {
+  if constexpr (NL == 1) { const float2 t = *reinterpret_cast<const float2 *>(p); a[0] = t.x; b[0] = t.y; }
+  else {
+#pragma unroll
+    for (int q = 0; q < NL / 2; ++q) {
+      const float4 t = *reinterpret_cast<const float4 *>(p + 4 * q);
+      a[2 * q] = t.x; b[2 * q] = t.y; a[2 * q + 1] = t.z; b[2 * q + 1] = t.w;
+    }
+  }
+}
+template <int NL>
+__device__ __forceinline__ void st_pairs(float *p, const float (&a)[NL], const float (&b)[NL]) {
+  if constexpr (NL == 1) *reinterpret_cast<float2 *>(p) = make_float2(a[0], b[0]);
+  else {
+#pragma unroll
+    for (int q = 0; q < NL / 2; ++q) *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(a[2 * q], b[2 * q], a[2 * q + 1], b[2 * q + 1]);
+  }
+}
+
+// per-frame emissions, linear: y[j] = exp(x[label[i]] - rowmax) (0 beyond label_length), bl = exp(x[blank] - rowmax)
+template <int NL>
+struct Emis {
+  float y[NL];
+  float bl;
+};
+template <int NL, class LDt>
+__device__ __forceinline__ void read_E(const float *row, int lane, Emis<NL> &e) {
+  ld_slots<NL>(row + lane * NL, e.y);
+  e.bl = row[LDt::UP];  // same address in every lane: LDS broadcast
+}
+
+// one lattice row of the OTHER direction in this chain's slot order (R row)
+template <int KIND, int NL>
+struct RRow {
+  float a[NL];  // classic: closed part / simplified: the state
+  float b[NL];  // classic: open part
+  float tx;     // state outside the slot range
+  int kt;       // its exponent
+};
+// Both kinds use the pair layout (simplified: second element unused): the R data of a lane then occupies exactly the 2 NL
+// floats its S row entry overwrites in place.  With a packed simplified row, lane L's S entry would overlap the R data of
+// lanes 2L and 2L+1 -- and nothing orders one lane's store against ANOTHER lane's earlier load (the compiler hoisted a
+// piece of the store above the load; per thread the two never alias).
+template <int KIND, int NL, class LDt>
+__device__ __forceinline__ void read_R(const float *row, int lane, RRow<KIND, NL> &r) {
+  ld_pairs<NL>(row + 2 * lane * NL, r.a, r.b);
+  const float2 t = *reinterpret_cast<const float2 *>(row + 2 * LDt::UP);
+  r.tx = t.x; r.kt = __float_as_int(t.y);
+}
+template <int KIND, int NL, class LDt>
+__device__ __forceinline__ void write_R(float *row, float *dump, int lane, const float (&a)[NL], const float (&b)[NL], float tx, int kt) {
+  st_pairs<NL>(row + 2 * lane * NL, a, b);
+  float *tq = (lane == 0) ? row + 2 * LDt::UP : dump + (lane & 31) * 2;  // lanes > 0 write a sink
+  *reinterpret_cast<float2 *>(tq) = make_float2(tx, __int_as_float(kt));
+}
+
+// ------------------------------------------------------------------------------------------------
+// The lattice state of one direction: mantissas + one exponent per lane.  Slot i = lane*NL + j is label position i.
+//   classic    A (DIR 0): c[j] = closed(l=i+1), o[j] = open(l=i+1), cx = closed(l=0)
+//              B (DIR 1): c[j] = closed(l=i),   o[j] = open(l=i+1), cx = closed(l=UP)
+//   simplified A: c[j] = a(l=i+1), cx = a(l=0);   B: c[j] = b(l=i), cx = b(l=UP)
+// true value = mantissa * 2^k (lanes) / 2^kx (cx).  dk = (exponent of the upstream neighbour) - k: what the one value a
+// lane receives per step has to be shifted by (upstream = previous lane for A, next lane for B; cx for the first / last).
+// ------------------------------------------------------------------------------------------------
+template <int KIND, int NL, int DIR>
+struct Chain {
+  float c[NL], o[NL], cx;
+  int k, kx, dk;
+  bool norep[NL], norep_next[NL];
+  int flag;
+
+  __device__ __forceinline__ void init_labels(const Problem &p, int b, int lane, int ll) {
+    const int32_t *lab = p.labels + (long)b * p.label_stride;
+    auto tok = [&](int i) -> int { return (i >= 0 && i < ll) ? ((i < p.label_stride) ? lab[i] : p.blank) : -1 - (i < 0); };
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int i = lane * NL + j;
+      const int tk = tok(i);
+      norep[j] = (i == 0) || tk != tok(i - 1);
+      norep_next[j] = tok(i + 1) != tk;
+      c[j] = 0.f;
+      o[j] = 0.f;
+    }
+    cx = 0.f; k = DEAD; kx = DEAD; dk = 0; flag = 0;
+  }
+
+  // starting state: alpha[0] = delta(closed(l=0)) / beta[len] = delta(closed(l=ll)) + delta(open(l=ll))
+  template <int LV>
+  __device__ __forceinline__ void start(int lane, int ll, int UP) {
+    if constexpr (DIR == 0) {
+      cx = 1.f; kx = 0;
+    } else {
+      if (ll == UP) { cx = 1.f; kx = 0; }
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        const int i = lane * NL + j;
+        if (i == ll) { c[j] = 1.f; k = 0; }
+        if (KIND == 0 && i == ll - 1) { o[j] = 1.f; k = 0; }
+      }
+    }
+    renorm<LV>();
+    flag = 0;
+  }
+
+  // one lattice step (the recursions of Side::step in ctc_fused_common.h with log-sum-exp -> +, + -> *)
+  __device__ __forceinline__ void step(const Emis<NL> &e) {
+    const float bl = e.bl;
+    if constexpr (KIND == 0 && DIR == 0) {
+      float m[NL], x[NL];
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        m[j] = c[j] + o[j];
+        x[j] = norep_next[j] ? m[j] : c[j];
+      }
+      const float xin0 = ldexp_f(from_prev_lane(x[NL - 1], cx), dk);
+#pragma unroll
+      for (int j = NL - 1; j >= 0; --j) {
+        const float xin = (j == 0) ? xin0 : x[j - 1];
+        o[j] = e.y[j] * (o[j] + xin);
+        c[j] = bl * m[j];
+      }
+      cx *= bl;
+    } else if constexpr (KIND == 0 && DIR == 1) {
+      float h[NL], ee[NL], pn[NL], x[NL];
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        h[j] = bl * c[j];
+        ee[j] = e.y[j] * o[j];
+        pn[j] = h[j] + ee[j];
+        x[j] = norep[j] ? pn[j] : h[j];
+      }
+      cx *= bl;
+      const float xinl = ldexp_f(from_next_lane(x[0], cx), dk);
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        const float xin = (j == NL - 1) ? xinl : x[j + 1];
+        o[j] = xin + ee[j];
+        c[j] = pn[j];
+      }
+    } else if constexpr (KIND == 1 && DIR == 0) {
+      const float pin0 = ldexp_f(from_prev_lane(c[NL - 1], cx), dk);
+#pragma unroll
+      for (int j = NL - 1; j >= 0; --j) {
+        const float pin = (j == 0) ? pin0 : c[j - 1];
+        c[j] = bl * c[j] + e.y[j] * pin;
+      }
+      cx *= bl;
+    } else {
+      const float nin = ldexp_f(from_next_lane(c[0], cx), dk);
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        const float nx = (j == NL - 1) ? nin : c[j + 1];
+        c[j] = bl * c[j] + e.y[j] * nx;
+      }
+      cx *= bl;
+    }
+  }
+
+  // per-lane renormalisation: k <- exponent of the lane maximum (lanes without mass adopt the upstream exponent - GAP so
+  // that what flows in during the next period is representable), cx to its own exponent, dk refreshed
+  template <int LV>
+  __device__ __forceinline__ void renorm() {
+    float m = c[0];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      m = fmaxf(m, c[j]);
+      if constexpr (KIND == 0) m = fmaxf(m, o[j]);
+    }
+    const bool live = m > 0.f;
+    const int fe = frexp_e(m);
+    const int e_own = live ? fe + k : DEAD;
+    const bool xlive = cx > 0.f;
+    const int ex = xlive ? frexp_e(cx) + kx : DEAD;
+    int kn = e_own;
+#pragma unroll
+    for (int lv = 0; lv < LV; ++lv) {
+      const int nb = (DIR == 0) ? from_prev_lane_i(kn, ex) : from_next_lane_i(kn, ex);
+      kn = imax(kn, nb - GAP);
+    }
+    kn = imax(kn, DEAD);
+    const int d = k - kn;
+    // D3: own live values crushed by a much larger inflow scale; D4: decayed by more than 2^-DECAY_MAX, or live -> zero
+    flag |= (live && d < -DOWN_MAX ? 4 : 0) | (live && fe < -DECAY_MAX ? 8 : 0) | (!live && alive ? 16 : 0);
+#ifdef CTC_F6_DEBUG
+    ++cnt;
+    if (!live && alive && dbg0 == 0) { dbg0 = cnt; dbg1 = k; dbg2 = __float_as_int(mlast); }
+    mlast = m;
+#endif
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      c[j] = ldexp_f(c[j], d);
+      if constexpr (KIND == 0) o[j] = ldexp_f(o[j], d);
+    }
+    k = kn;
+    cx = ldexp_f(cx, kx - ex);
+    kx = ex;
+    dk = ((DIR == 0) ? from_prev_lane_i(k, kx) : from_next_lane_i(k, kx)) - k;
+    alive = live;
+  }
+  bool alive = false;  // the lane had mass at its last renormalisation
+#ifdef CTC_F6_DEBUG
+  int cnt = 0, dbg0 = 0, dbg1 = 0, dbg2 = 0;
+  float mlast = 0.f;
+#endif
+  // OR of the lanes' flags (wave-uniform)
+  __device__ __forceinline__ int flag_or() const {
+    int f = 0;
+#pragma unroll
+    for (int bit = 4; bit <= 16; bit <<= 1) f |= (__builtin_amdgcn_ballot_w64((flag & bit) != 0) != 0) ? bit : 0;
+    return f;
+  }
+
+  // the state in the slot order of the OTHER direction (what that direction's main chain multiplies with):
+  //   DIR 1 (B-native) -> A order: slot i = (state_c(l=i+1) [, open(l=i+1)]), outside = state_c(l=0)
+  //   DIR 0 (A-native) -> B order: slot i = (state_c(l=i)   [, open(l=i+1)]), outside = state_c(l=UP)
+  __device__ __forceinline__ void other_order(float (&cs)[NL], float &tx, int &kt) const {
+    if constexpr (DIR == 0) {
+#pragma unroll
+      for (int j = NL - 1; j > 0; --j) cs[j] = c[j - 1];
+      cs[0] = ldexp_f(from_prev_lane(c[NL - 1], cx), dk);
+      tx = readlane_f(c[NL - 1], 63);
+      kt = readlane_i(k, 63);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NL - 1; ++j) cs[j] = c[j + 1];
+      cs[NL - 1] = ldexp_f(from_next_lane(c[0], cx), dk);
+      tx = readlane_f(c[0], 0);
+      kt = readlane_i(k, 0);
+    }
+  }
+};
+
+// checkpoint row in HBM: the chain's NATIVE state.  rows: [slot][SRS] floats (pairs (c, o) for classic, c for simplified,
+// tail = (cx, kx)); kexp: [slot][64] per-lane exponents.
+template <int KIND, int NL, int DIR>
+__device__ __forceinline__ void spill(const Chain<KIND, NL, DIR> &S, float *__restrict__ rows, int *__restrict__ kexp,
+                                      int slot, int SRS, int UP, int lane) {
+  float *row = rows + (long)slot * SRS;
+  if constexpr (KIND == 0) st_pairs<NL>(row + 2 * lane * NL, S.c, S.o);
+  else st_slots<NL>(row + lane * NL, S.c);
+  if (lane == 0) *reinterpret_cast<float2 *>(row + (KIND == 0 ? 2 : 1) * UP) = make_float2(S.cx, __int_as_float(S.kx));
+  kexp[slot * 64 + lane] = S.k;
+}
+template <int KIND, int NL>
+struct CkRow {
+  float c[NL], o[NL], cx;
+  int k, kx;
+};
+template <int KIND, int NL>
+__device__ __forceinline__ void load_ck(CkRow<KIND, NL> &r, const float *__restrict__ rows, const int *__restrict__ kexp, int slot,
+                                        int SRS, int UP, int lane) {
+  const float *row = rows + (long)slot * SRS;
+  if constexpr (KIND == 0) ld_pairs<NL>(row + 2 * lane * NL, r.c, r.o);
+  else {
+    ld_slots<NL>(row + lane * NL, r.c);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) r.o[j] = 0.f;
+  }
+  const float2 t = *reinterpret_cast<const float2 *>(row + (KIND == 0 ? 2 : 1) * UP);
+  r.cx = t.x; r.kx = __float_as_int(t.y);
+  r.k = kexp[slot * 64 + lane];
+}
+template <int KIND, int NL, int DIR>
+__device__ __forceinline__ void restore(Chain<KIND, NL, DIR> &S, const CkRow<KIND, NL> &r) {
+#pragma unroll
+  for (int j = 0; j < NL; ++j) { S.c[j] = r.c[j]; S.o[j] = r.o[j]; }
+  S.cx = r.cx; S.k = r.k; S.kx = r.kx;
+  S.dk = ((DIR == 0) ? from_prev_lane_i(S.k, S.kx) : from_next_lane_i(S.k, S.kx)) - S.k;
+  float m = 0.f;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) m = fmaxf(m, fmaxf(r.c[j], r.o[j]));
+  S.alive = m > 0.f;  // (a lane that only adopted its neighbour's exponent has no mass yet)
+}
+
+// ------------------------------------------------------------------------------------------------
+// Logits rows: loads / stores / softmax statistics / emission gather.  Wraps Side<> of ctc_fused_common.h for the
+// format-specific row accesses (contiguous or strided float32, bfloat16, unaligned rows).
+// ------------------------------------------------------------------------------------------------
+template <int KIND, int NL, int VPL, int XT>
+struct Rows {
+  static constexpr int V = 256 * VPL;
+  Side<KIND, NL, VPL, 0, true, XT> io;  // load_x / store_g / zero_rows only
+  int tokoff[NL];                       // byte offset of label[i] in the LDS copy of the row (pad slot beyond label_length)
+  float mb[4 * VPL];                    // 1.0 at this lane's element that is the blank column
+  bool valid[NL];                       // slot i < label_length
+  float *xs, *bins;
+  int lane, blank;
+  float dl;
+
+  __device__ __forceinline__ void init(const Problem &p, int b, int lane_, int ll, const float *d_loss, float *grad) {
+    lane = lane_; blank = p.blank;
+    io.lane = lane_;
+    if constexpr (XT != 2) {
+      io.xbase = p.logits + (long)b * p.xsb;
+      io.gbase = grad + (long)b * p.gsb;
+    } else {
+      io.xbase = reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(p.logits) + (long)b * p.xsb);
+      io.gbase = reinterpret_cast<float *>(reinterpret_cast<unsigned short *>(grad) + (long)b * p.gsb);
+    }
+    io.xst = p.xst; io.gst = p.gst; io.Vr = p.V;
+    dl = d_loss ? d_loss[b] : 1.0f;
+    const int32_t *lab = p.labels + (long)b * p.label_stride;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int i = lane * NL + j;
+      const int tk = (i < ll) ? ((i < p.label_stride) ? lab[i] : p.blank) : -1;
+      valid[j] = i < ll;
+      tokoff[j] = 4 * ((tk >= 0 && tk < p.V && tk < V && tk != p.blank) ? tk : V);
+    }
+#pragma unroll
+    for (int e = 0; e < 4 * VPL; ++e) mb[e] = (256 * (e / 4) + lane * 4 + (e & 3) == p.blank) ? 1.f : 0.f;
+  }
+
+  // exp(x - rowmax) of this lane's elements from the recorded statistic mxl = rowmax * log2(e)
+  __device__ __forceinline__ void expo(const float4 (&xr)[VPL], float mxl, float4 (&ev)[VPL]) const {
+#pragma unroll
+    for (int q = 0; q < VPL; ++q)
+      ev[q] = make_float4(fexp2(fmaf(xr[q].x, LOG2E, -mxl)), fexp2(fmaf(xr[q].y, LOG2E, -mxl)),
+                          fexp2(fmaf(xr[q].z, LOG2E, -mxl)), fexp2(fmaf(xr[q].w, LOG2E, -mxl)));
+  }
+  // emission gather through an LDS copy of the exponentiated row (base_loss.py:328-344, 365-371)
+  __device__ __forceinline__ void gather(const float4 (&ev)[VPL], Emis<NL> &e) const {
+#pragma unroll
+    for (int q = 0; q < VPL; ++q)
+      *reinterpret_cast<float4 *>(xs + 256 * q + lane * 4) = make_float4(ev[q].x, ev[q].y, ev[q].z, ev[q].w);
+    const char *bb = reinterpret_cast<const char *>(xs);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) e.y[j] = *reinterpret_cast<const float *>(bb + tokoff[j]);
+    e.bl = xs[blank];
+  }
+
+  // Q frames at once (phase 1): row maximum and sum of exponentials by batched DPP reductions (ctc_dpp_batch.h), then the
+  // gathers.  Outputs per frame: emissions, mxl = rowmax * log2 e, inv = 1 / sum exp, l2s = log2 sum exp.
+  template <int Q>
+  __device__ __forceinline__ void emit_n(const float4 (&xr)[Q][VPL], Emis<NL> (&e)[Q], float (&mxl)[Q], float (&inv)[Q], float (&l2s)[Q]) const {
+    float m[Q];
+#pragma unroll
+    for (int f = 0; f < Q; ++f) {
+      m[f] = fmaxf(fmaxf(xr[f][0].x, xr[f][0].y), fmaxf(xr[f][0].z, xr[f][0].w));
+#pragma unroll
+      for (int q = 1; q < VPL; ++q) m[f] = fmaxf(m[f], fmaxf(fmaxf(xr[f][q].x, xr[f][q].y), fmaxf(xr[f][q].z, xr[f][q].w)));
+    }
+    dpp_max_n<Q>(m);
+    float4 ev[Q][VPL];
+    float sm[Q];
+#pragma unroll
+    for (int f = 0; f < Q; ++f) {
+      float mx = readlane_f(m[f], 63);
+      mx = (mx == -INFINITY) ? 0.f : mx;
+      mxl[f] = mx * LOG2E;
+      expo(xr[f], mxl[f], ev[f]);
+      sm[f] = 0.f;
+#pragma unroll
+      for (int q = 0; q < VPL; ++q) sm[f] += (ev[f][q].x + ev[f][q].y) + (ev[f][q].z + ev[f][q].w);
+    }
+    dpp_sum_n<Q>(sm);
+#pragma unroll
+    for (int f = 0; f < Q; ++f) {
+      const float s = readlane_f(sm[f], 63);
+      l2s[f] = flog2(s);
+      inv[f] = __builtin_amdgcn_rcpf(s);
+    }
+#pragma unroll
+    for (int f = 0; f < Q; ++f) gather(ev[f], e[f]);  // LDS operations of a wavefront execute in program order: one copy serves all
+  }
+
+  // gradient row of frame t from the S row of the main chain: sq[0] = blank posterior of this lane, sq[1 + j] = token
+  // posterior of slot j, both in units of 2^-30; ev = exp(x - rowmax) of this lane's elements, inv = 1 / sum exp
+  __device__ __forceinline__ void grad_row(int t, float qb, const float (&qt)[NL], const float4 (&ev)[VPL], float inv) const {
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) *reinterpret_cast<float4 *>(bins + 256 * q + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    char *bb = reinterpret_cast<char *>(bins);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) atomicAdd(reinterpret_cast<unsigned *>(bb + tokoff[j]), (unsigned)(qt[j] + 0.5f));
+    const float c1 = -dl * 9.31322574615478515625e-10f;
+    const float c2 = dl * inv;
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) {
+      const uint4 pu = *reinterpret_cast<const uint4 *>(bins + 256 * q + lane * 4);
+      const float4 pq = make_float4((float)pu.x + mb[4 * q] * qb, (float)pu.y + mb[4 * q + 1] * qb,
+                                    (float)pu.z + mb[4 * q + 2] * qb, (float)pu.w + mb[4 * q + 3] * qb);
+#ifdef CTC_F6_NOSTORE  // experiment: no gradient traffic (results are wrong)
+      if (pq.x * c1 + c2 * ev[q].x == 123.456f)
+#endif
+      io.store_g(t, q, make_float4(pq.x * c1 + c2 * ev[q].x, pq.y * c1 + c2 * ev[q].y, pq.z * c1 + c2 * ev[q].z, pq.w * c1 + c2 * ev[q].w));
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// E stage of phase 1, shared by the helpers and the recompute wavefronts (which have no lattice work before the meeting
+// point): positions P0 .. P0+NQ-1 of every block of side SIDE.  Records (mxl, inv) per frame for phase 2, accumulates
+// log2 sum exp of its frames in double and tracks the smallest needed emission (D2).
+// ------------------------------------------------------------------------------------------------
+#ifndef CTC_F6_PFD
+#define CTC_F6_PFD 2
+#endif
+#ifndef CTC_F6_X
+#define CTC_F6_X 2
+#endif
+#ifndef CTC_F6_Y
+#define CTC_F6_Y 2
+#endif
+template <int BLK, int NH, int NL>
+struct P1Split {
+  static constexpr int X = NH == 4 ? CTC_F6_X : BLK / 3, Y = NH == 4 ? CTC_F6_Y : BLK / 3;
+  static constexpr int R = NH == 4 ? BLK - 2 * X - 2 * Y : BLK - X - Y;
+  static_assert(NH == 4 || NH == 2, "helpers per side");
+  static_assert(X >= 0 && Y >= 0 && R >= 0 && X <= 6 && Y <= 6 && R <= 6, "phase-1 split: at most 6 frames per worker");
+  static constexpr int count(int worker) {
+    if (NH == 4) return worker < 2 ? X : worker < 4 ? Y : R;
+    return worker == 0 ? X : worker == 1 ? Y : R;
+  }
+  static constexpr int first(int worker) {
+    int f = 0;
+    for (int w = 0; w < worker; ++w) f += count(w);
+    return f;
+  }
+};
+
+template <int KIND, int NL, int NH, int BLK, int VPL, int XT, int SIDE, int P0, int NQ>
+__device__ __forceinline__ void estage1(const Rows<KIND, NL, VPL, XT> &S, Lds<KIND, NL, NH, BLK, VPL> &lds, const Geo<BLK> &geo,
+                                        float2 *__restrict__ stats, float *dump, int lane, int wave
+#ifdef CTC_F6_STAMPS
+                                        , Stamps &st_
+#endif
+                                        ) {
+  using LD = Lds<KIND, NL, NH, BLK, VPL>;
+  const int len = geo.len;
+  const int nb = geo.nblocks(1, SIDE);
+  auto write_E = [&](float *row, const Emis<NL> &e) __attribute__((always_inline)) {
+    st_slots<NL>(row + lane * NL, e.y);
+    float *tq = (lane == 0) ? row + LD::UP : dump + lane;
+    *tq = e.bl;
+  };
+  auto fr = [&](int j, int d) -> int {  // frame at position d of this side's block j, clamped so prefetches stay legal
+    int jj = j < nb ? j : nb - 1;
+    jj = jj < 0 ? 0 : jj;
+    const int g = geo.absblock(1, SIDE, jj);
+    const int nv = geo.nvof(g);
+    int dd = d < nv ? d : nv - 1;
+    int t = geo.frame(SIDE, g, dd < 0 ? 0 : dd);
+    t = t < len ? t : len - 1;
+    return t < 0 ? 0 : t;
+  };
+  constexpr int NQA = NQ > 0 ? NQ : 1;
+  // logits rows are loaded PFD blocks ahead of their use (a block lasts ~2 us, an HBM load under load about as long: one
+  // block of look-ahead left the E stage waiting on memory for half of phase 1), in a ring of register sets addressed by
+  // (block mod PFD) at COMPILE time -- the loop is unrolled by PFD
+  constexpr int PFD = CTC_F6_PFD;
+  float4 xb[PFD][NQA][VPL];
+  static_for<0, PFD>([&](auto R) {
+    static_for<0, NQA>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      static_for<0, VPL>([&](auto W) { xb[decltype(R)::value][q][decltype(W)::value] = make_float4(0.f, 0.f, 0.f, 0.f); });
+      if (NQ > 0 && nb > 0) S.io.load_x(xb[decltype(R)::value][q], fr(decltype(R)::value, P0 + q));
+    });
+  });
+  double acc = 0.0;
+  float zmin[NL], zb = 1.0f;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) zmin[j] = 1.0f;
+  auto track = [&](const Emis<NL> &e, float l2s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) zmin[j] = fminf(zmin[j], e.y[j]);
+    zb = fminf(zb, e.bl);
+    acc += (double)l2s;
+  };
+  auto body = [&](auto R, int it) __attribute__((always_inline)) {
+    constexpr int r = decltype(R)::value;  // = it mod PFD
+    const int j = it;
+    if (NQ > 0 && j < nb) {
+      const int g = geo.absblock(1, SIDE, j);
+      const int nv = geo.nvof(g);
+      float(*E)[LD::ES] = lds.E[SIDE][j % 3];
+      float smx = 0.f, sinv = 0.f;  // lane d keeps the statistics of position d of the block
+      if (nv == BLK) {
+        if constexpr (NQ > 0) {
+          float4 xq[NQA][VPL];
+          Emis<NL> e[NQA];
+          float mxl[NQA], inv[NQA], l2s[NQA];
+          static_for<0, NQA>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            static_for<0, VPL>([&](auto W) {
+              constexpr int w = decltype(W)::value;
+              xq[q][w] = make_float4(xb[r][q][w].x, xb[r][q][w].y, xb[r][q][w].z, xb[r][q][w].w);
+            });
+          });
+          S.template emit_n<NQA>(xq, e, mxl, inv, l2s);
+          static_for<0, NQA>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            write_E(E[P0 + q], e[q]);
+            track(e[q], l2s[q]);
+            smx = (lane == P0 + q) ? mxl[q] : smx;
+            sinv = (lane == P0 + q) ? inv[q] : sinv;
+          });
+        }
+      } else {
+        for (int q = 0; q < NQ; ++q) {
+          const int d = P0 + q;
+          if (d < nv) {
+            float4 xr[1][VPL];
+            S.io.load_x(xr[0], geo.frame(SIDE, g, d));
+            Emis<NL> e[1];
+            float mxl[1], inv[1], l2s[1];
+            S.template emit_n<1>(xr, e, mxl, inv, l2s);
+            write_E(E[d], e[0]);
+            track(e[0], l2s[0]);
+            smx = (lane == d) ? mxl[0] : smx;
+            sinv = (lane == d) ? inv[0] : sinv;
+          }
+        }
+      }
+      static_for<0, NQA>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        S.io.load_x(xb[r][q], fr(j + PFD, P0 + q));
+      });
+      if (lane >= P0 && lane < P0 + NQ && lane < nv) stats[geo.frame(SIDE, g, lane)] = make_float2(smx, sinv);
+    }
+    F6_BARRIER();
+  };
+  for (int it0 = 0; it0 <= geo.NB; it0 += PFD) {
+    static_for<0, PFD>([&](auto R) {
+      if (it0 + decltype(R)::value <= geo.NB) body(R, it0 + decltype(R)::value);
+    });
+  }
+  // D2: a needed emission below 2^-100 of its row maximum (also catches NaN: the comparison is false)
+  bool bad = !(zb >= EMIS_MIN) || !(acc - acc == 0.0);  // (a NaN or +inf logit makes the row sum, hence acc, non-finite)
+#pragma unroll
+  for (int j = 0; j < NL; ++j) bad = bad || (S.valid[j] && !(zmin[j] >= EMIS_MIN));
+  if (NQ > 0 && nb > 0 && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(&lds.flag, 2);
+  if (lane == 0) lds.l2s[wave] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// main chain
+// ------------------------------------------------------------------------------------------------
+template <int KIND, int NL, int NH, int BLK, int VPL, int DIR>
+__device__ __forceinline__ void run_main(const Problem &p, const Layout &L, float *__restrict__ alpha_ws,
+                                         float *__restrict__ beta_ws, int *__restrict__ kexp_ws, double *__restrict__ logp_ws,
+                                         float *__restrict__ loss, int *__restrict__ flag_ws,
+                                         Lds<KIND, NL, NH, BLK, VPL> &lds, const Geo<BLK> &geo, bool want_grad, int b) {
+  using LD = Lds<KIND, NL, NH, BLK, VPL>;
+  using CD = Cad<BLK, NL>;
+  constexpr int RN = CD::RN, LV = CD::LV;
+  Chain<KIND, NL, DIR> S;
+  const int lane = threadIdx.x & 63;
+  const int T = p.T, UP = L.UP, SRS = L.SRS;
+  const int len = geo.len;
+  int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  const bool shape_ok = (ll <= p.U);
+  if (!shape_ok) ll = 0;
+  const int nslot = (T + 5) / 6 + 3;  // checkpoint slots per direction (sized for the shortest block length)
+  float *own_rows = (DIR == 0 ? alpha_ws : beta_ws) + (long)b * (T + 1) * SRS;
+  const float *oth_rows = (DIR == 0 ? beta_ws : alpha_ws) + (long)b * (T + 1) * SRS;
+  int *own_k = kexp_ws + ((long)b * 2 + DIR) * nslot * 64;
+  const int *oth_k = kexp_ws + ((long)b * 2 + (1 - DIR)) * nslot * 64;
+  S.init_labels(p, b, lane, ll);
+  S.template start<LV>(lane, ll, UP);
+  float *dump = lds.dump[DIR];
+  (void)dump;
+  int *flag_ws_dbg = flag_ws;
+  (void)flag_ws_dbg;
+  F6_STAMP_DECL
+
+  // ================= phase 1: lattice steps, one checkpoint row per block =================
+  {
+    const int nb = geo.nblocks(1, DIR);
+    for (int it = 0; it <= geo.NB; ++it) {
+      const int j = it - 1;
+      if (j >= 0 && j < nb) {
+        const int g = geo.absblock(1, DIR, j);
+        const int nv = geo.nvof(g);
+        const float(*E)[LD::ES] = lds.E[DIR][j % 3];
+        spill<KIND, NL, DIR>(S, own_rows, own_k, geo.slot(DIR == 0 ? BLK * g : BLK * g + nv), SRS, UP, lane);
+        if (nv == BLK) {
+          // the emission rows of the whole block go to registers first: the sequential chain never waits for an LDS round
+          // trip (with the read next to its use every frame paid one, ~100 of its ~190 cycles)
+          Emis<NL> eb[BLK];
+          static_for<0, BLK>([&](auto D) { read_E<NL, LD>(E[decltype(D)::value], lane, eb[decltype(D)::value]); });
+          static_for<0, BLK>([&](auto D) {
+            constexpr int d = decltype(D)::value;
+            S.step(eb[d]);
+            if ((d + 1) % RN == 0) S.template renorm<LV>();
+          });
+        } else {
+          for (int d = 0; d < nv; ++d) {
+            Emis<NL> e;
+            read_E<NL, LD>(E[d], lane, e);
+            S.step(e);
+            if ((d + 1) % RN == 0 || d == nv - 1) S.template renorm<LV>();
+          }
+        }
+      }
+      F6_BARRIER();
+    }
+  }
+  spill<KIND, NL, DIR>(S, own_rows, own_k, geo.slot(geo.tm), SRS, UP, lane);  // alpha[tm] / beta[tm]: the meeting row
+#ifdef CTC_F6_DEBUG
+  {
+    int *dbg = flag_ws + p.B + ((long)b * 2 + DIR) * 256 + 0;  // diagnostic builds: per lane (renorm count at death, k, last max)
+    dbg[lane] = S.dbg0; dbg[64 + lane] = S.dbg1; dbg[128 + lane] = S.dbg2; dbg[192 + lane] = S.k;
+  }
+#endif
+  {
+    const int f = S.flag_or();  // D3 / D4 of phase 1
+    if (f != 0 && lane == 0) atomicOr(&lds.flag, f);
+  }
+
+  // ================= meeting point =================
+  __syncthreads();  // full drain: the checkpoint rows of both chains are visible to the workgroup
+  if constexpr (DIR == 0) {
+    // P = sum over states of alpha[tm] beta[tm]: B's native row shifted into A's slot order (closed parts come from the
+    // next slot), every product with its own exponent, reduced with a common exponent EX
+    CkRow<KIND, NL> r;
+    load_ck<KIND, NL>(r, oth_rows, oth_k, geo.slot(geo.tm), SRS, UP, lane);
+    const int kn = from_next_lane_i(r.k, r.kx);                  // exponent of the value shifted in from the next lane
+    const float cn = from_next_lane(r.c[0], r.cx);
+    float t1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      if (j < NL - 1) t1 += S.c[j] * r.c[j + 1];
+      if constexpr (KIND == 0) t1 += S.o[j] * r.o[j];
+    }
+    const float t2 = S.c[NL - 1] * cn;
+    const float t0 = (lane == 0) ? S.cx * readlane_f(r.c[0], 0) : 0.f;
+    const int k0 = readlane_i(r.k, 0);
+    const int e1 = (t1 > 0.f) ? frexp_e(t1) + S.k + r.k : DEAD;
+    const int e2 = (t2 > 0.f) ? frexp_e(t2) + S.k + kn : DEAD;
+    const int e0 = (t0 > 0.f) ? frexp_e(t0) + S.kx + k0 : DEAD;
+    const int EX = (int)wave_max_dpp((float)imax(e1, imax(e2, e0)));  // |values| <= 2^24: exact in float32
+    float s = 0.f;
+    if (t1 > 0.f) s += ldexp_f(t1, S.k + r.k - EX);
+    if (t2 > 0.f) s += ldexp_f(t2, S.k + kn - EX);
+    if (t0 > 0.f) s += ldexp_f(t0, S.kx + k0 - EX);
+    s = wave_sum_dpp(s);
+    // D1: P == 0 / inf / NaN (or nothing alive at all)
+    const bool okP = shape_ok && EX > DEAD / 2 && s > 0.f && s < 3.0e38f;
+    double sl2 = 0.0;
+    for (int w = 2; w < LD::NW; ++w) sl2 += lds.l2s[w];
+    // D3 / D4 (bits 4, 8, 16) send a loss-only call to the log-domain kernel; with a gradient the mass check D6 decides
+    const int fl = (lds.flag & (want_grad ? 3 : 31)) | (okP ? 0 : 1);
+    if (lane == 0) {
+      const double dlogp = (double)flog2(s) + (double)EX - sl2;
+      logp_ws[b] = okP ? dlogp : -INFINITY;
+      loss[b] = okP ? (float)(-dlogp * LN2_D) : INFINITY;
+      const int fe = frexp_e(s);
+      lds.lp_int = EX + fe;
+      lds.cf = __builtin_amdgcn_rcpf(ldexp_f(s, -fe));   // 1 / mantissa, in (1, 2]
+      lds.feasible = (fl == 0);
+      lds.flag = fl;
+    }
+  }
+  __syncthreads();
+  const bool go = lds.feasible != 0;
+  if (!want_grad || !go) {  // loss only, or flagged (the log-domain kernel redoes this utterance): every role leaves here
+    if (DIR == 0 && lane == 0) flag_ws[b] = lds.flag;
+    return;
+  }
+  const int lp_int = lds.lp_int;
+  const float cf30 = ldexp_f(lds.cf, 30);
+  F6_STAMP_PHASE2
+
+  // ================= phase 2: everything from LDS =================
+  {
+    const int nb = geo.nblocks(2, DIR);
+    int kflag = 0;
+    for (int it = 0; it <= geo.NB + 2; ++it) {
+      const int j = it - 2;
+      if (j >= 0 && j < nb) {
+        const int g = geo.absblock(2, DIR, j);
+        const int nv = geo.nvof(g);
+        const float(*E)[LD::ES] = lds.E[DIR][j % 3];
+        float(*RR)[LD::RS] = lds.R[DIR][j % 3];
+        const int(*KG)[64] = lds.kg[DIR][j % 3];
+        // exponent group of the R row at position d: rows are written BEFORE the recompute chain renormalises, s steps
+        // after its checkpoint -> group max(s-1, 0) / RN.  s = nv-1-d (A, simplified B) / nv-d (classic B).
+        auto grp = [&](int d) -> int {
+          const int s = (KIND == 0 && DIR == 1) ? nv - d : nv - 1 - d;
+          return (s > 0 ? s - 1 : 0) / RN;
+        };
+        int q = -1, kR = DEAD;
+        float KL = 0.f;
+        auto setK = [&]() __attribute__((always_inline)) {
+          const int kk = S.k + kR - lp_int;
+          kflag |= (kk > KK_MAX);
+          KL = ldexp_f(cf30, imin(kk, KK_MAX));
+        };
+        auto one = [&](int d, int qd, bool ren, const Emis<NL> &e, const RRow<KIND, NL> &r, int kRq) __attribute__((always_inline)) {
+          if (qd != q) { q = qd; kR = kRq; setK(); }
+          float qb, qt[NL], p0;
+          if constexpr (KIND == 0) {
+            if constexpr (DIR == 0) S.step(e);  // A: posterior of frame t from alpha[t+1], beta[t+1]
+            // (A renormalises after the products below; its exponent is still the one KL was built from.  Products first,
+            // then the scale: a mantissa product may underflow -- by then it is below 2^-16 units -- but never overflows)
+            qb = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < NL; ++jj) { qb += S.c[jj] * r.a[jj]; qt[jj] = (S.o[jj] * r.b[jj]) * KL; }
+            qb *= KL;
+            p0 = S.cx * r.tx;
+          } else if constexpr (DIR == 0) {
+            const float pin0 = ldexp_f(from_prev_lane(S.c[NL - 1], S.cx), S.dk);
+            qb = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < NL; ++jj) {
+              const float pin = (jj == 0) ? pin0 : S.c[jj - 1];
+              qb += S.c[jj] * r.a[jj];
+              qt[jj] = ((pin * e.y[jj]) * r.a[jj]) * KL;
+            }
+            qb *= e.bl * KL;
+            p0 = S.cx * e.bl * r.tx;
+          } else {
+            const float nin = ldexp_f(from_next_lane(S.c[0], S.cx), S.dk);
+            qb = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < NL; ++jj) {
+              const float nx = (jj == NL - 1) ? nin : S.c[jj + 1];
+              qb += S.c[jj] * r.a[jj];
+              qt[jj] = ((nx * e.y[jj]) * r.a[jj]) * KL;
+            }
+            qb *= e.bl * KL;
+            p0 = S.cx * e.bl * r.tx;
+          }
+          // the state outside the slot range (uniform): into lane 0's blank part
+          const int k0 = S.kx + r.kt - lp_int;
+          kflag |= (p0 > 0.f && k0 > KK_MAX);
+          const float q0 = p0 * ldexp_f(cf30, imin(k0, KK_MAX));
+          qb += (lane == 0) ? q0 : 0.f;
+#ifdef CTC_F6_DEBUG2
+          if (DIR == 0 && j == 0 && d < 4 && NL == 2) {  // main A, first phase-2 block, frames d = 0..3: what goes into the S row
+            int *dbg = flag_ws + p.B + (long)b * 2048;
+            dbg[(d * 8 + 0) * 64 + lane] = __float_as_int(qb); dbg[(d * 8 + 1) * 64 + lane] = __float_as_int(qt[0]);
+            dbg[(d * 8 + 2) * 64 + lane] = __float_as_int(qt[NL - 1]); dbg[(d * 8 + 3) * 64 + lane] = S.k;
+            dbg[(d * 8 + 4) * 64 + lane] = kR; dbg[(d * 8 + 5) * 64 + lane] = __float_as_int(r.a[0]);
+            dbg[(d * 8 + 6) * 64 + lane] = __float_as_int(r.a[NL - 1]); dbg[(d * 8 + 7) * 64 + lane] = __float_as_int(S.c[0]);
+          }
+#endif
+          // S row in place of the R row: per lane [qb, qt[0..NL-1]] in a region of 2 NL floats
+          float *srow = RR[d] + 2 * lane * NL;
+          if constexpr (NL == 1) *reinterpret_cast<float2 *>(srow) = make_float2(qb, qt[0]);
+          else if constexpr (NL == 2) *reinterpret_cast<float4 *>(srow) = make_float4(qb, qt[0], qt[1], 0.f);
+          else {
+            *reinterpret_cast<float4 *>(srow) = make_float4(qb, qt[0], qt[1], qt[2]);
+            srow[4] = qt[3];
+          }
+          if constexpr (!(KIND == 0 && DIR == 0)) S.step(e);
+          if (ren) { S.template renorm<LV>(); setK(); }
+        };
+        if (nv == BLK) {
+          // emission rows of the whole block and the exponent groups up front, R rows PR frames ahead of their use
+          constexpr int PR = 3;
+          Emis<NL> eb[BLK];
+          RRow<KIND, NL> rb[BLK];
+          int kq[CD::NG];
+          static_for<0, CD::NG>([&](auto Q) { kq[decltype(Q)::value] = KG[decltype(Q)::value][lane]; });
+          static_for<0, PR>([&](auto D) { read_R<KIND, NL, LD>(RR[decltype(D)::value], lane, rb[decltype(D)::value]); });
+          static_for<0, BLK>([&](auto D) { read_E<NL, LD>(E[decltype(D)::value], lane, eb[decltype(D)::value]); });
+          static_for<0, BLK>([&](auto D) {
+            constexpr int d = decltype(D)::value;
+            if constexpr (d + PR < BLK) read_R<KIND, NL, LD>(RR[d + PR], lane, rb[d + PR]);
+            constexpr int s = (KIND == 0 && DIR == 1) ? BLK - d : BLK - 1 - d;
+            constexpr int qd = (s > 0 ? s - 1 : 0) / RN;
+            one(d, qd, (d + 1) % RN == 0, eb[d], rb[d], kq[qd]);
+          });
+        } else {
+          for (int d = 0; d < nv; ++d) {
+            Emis<NL> e;
+            read_E<NL, LD>(E[d], lane, e);
+            RRow<KIND, NL> r;
+            read_R<KIND, NL, LD>(RR[d], lane, r);
+            const int qd = grp(d);
+            one(d, qd, (d + 1) % RN == 0 || d == nv - 1, e, r, KG[qd][lane]);
+          }
+        }
+      }
+      F6_BARRIER();
+    }
+    (void)kflag;
+  }
+  __syncthreads();  // every role's phase-2 flags are in
+  if (DIR == 0 && lane == 0) flag_ws[b] = lds.flag;
+  F6_STAMP_DUMP(DIR);
+}
+
+// ------------------------------------------------------------------------------------------------
+// recompute chain of side SIDE (phase 2): runs the OTHER direction's recursion inside one block, from that direction's
+// checkpoint, and leaves the rows its main chain needs in LDS, in the main chain's slot order, with their exponents.
+//   SIDE A (needs beta[t+1] at frame t = BLK g + d)      : R[nv-1] = checkpoint beta[BLK g + nv]; step frames downward
+//   SIDE B classic (needs alpha[t+1] at t = BLK g + nv-1-d): step frames upward from alpha[BLK g], row after each step
+//   SIDE B simplified (needs a[t])                        : row before each step
+// ------------------------------------------------------------------------------------------------
+template <int KIND, int NL, int NH, int BLK, int VPL, int SIDE, int XT>
+__device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L, const float *__restrict__ alpha_ws,
+                                              const float *__restrict__ beta_ws, const int *__restrict__ kexp_ws,
+                                              float2 *__restrict__ stats_ws, Lds<KIND, NL, NH, BLK, VPL> &lds,
+                                              const Geo<BLK> &geo, bool want_grad, int b, int *flag_ws_dbg) {
+  constexpr int RDIR = 1 - SIDE;  // direction of the recursion this wave runs
+  F6_STAMP_DECL
+  using LD = Lds<KIND, NL, NH, BLK, VPL>;
+  using CD = Cad<BLK, NL>;
+  constexpr int RN = CD::RN, LV = CD::LV;
+  const int lane = threadIdx.x & 63;
+  const int T = p.T, UP = L.UP, SRS = L.SRS;
+  int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  if (ll > p.U) ll = 0;
+  const int nslot = (T + 5) / 6 + 3;
+  const float *ck_rows = (RDIR == 0 ? alpha_ws : beta_ws) + (long)b * (T + 1) * SRS;
+  const int *ck_k = kexp_ws + ((long)b * 2 + RDIR) * nslot * 64;
+  float *dump = lds.dump[2 + SIDE];
+
+  {  // phase 1: nothing to recompute yet -- this wavefront works the E stage of its side
+    using SP = P1Split<BLK, NH, NL>;
+    Rows<KIND, NL, VPL, XT> W;
+    W.init(p, b, lane, ll, nullptr, nullptr);
+    W.xs = lds.xcopy_r[SIDE];
+    if (lane == 0) W.xs[256 * VPL] = 0.f;  // pad slot of the gather copy: emission 0 for label positions beyond label_length
+    float2 *stats = stats_ws + (long)b * T;
+    estage1<KIND, NL, NH, BLK, VPL, XT, SIDE, SP::first(NH), SP::count(NH)>(W, lds, geo, stats, dump, lane, 2 + SIDE F6_ST_ARG);
+  }
+  __syncthreads();
+  __syncthreads();
+  if (!want_grad || lds.feasible == 0) return;
+  F6_STAMP_PHASE2
+
+  Chain<KIND, NL, RDIR> S;
+  S.init_labels(p, b, lane, ll);
+  const int nb = geo.nblocks(2, SIDE);
+  auto ck_slot = [&](int j) -> int {
+    int jj = j < nb ? j : nb - 1;
+    jj = jj < 0 ? 0 : jj;
+    const int g = geo.absblock(2, SIDE, jj);
+    const int t = (SIDE == 0) ? BLK * g + geo.nvof(g) : BLK * g;  // beta at the upper boundary / alpha at the lower one
+    return geo.slot(t < 0 ? 0 : t);
+  };
+  CkRow<KIND, NL> ck_next;
+  load_ck<KIND, NL>(ck_next, ck_rows, ck_k, ck_slot(0), SRS, UP, lane);
+  for (int it = 0; it <= geo.NB + 2; ++it) {
+    const int j = it - 1;
+    if (j >= 0 && j < nb) {
+      const int g = geo.absblock(2, SIDE, j);
+      const int nv = geo.nvof(g);
+      const float(*E)[LD::ES] = lds.E[SIDE][j % 3];
+      float(*RR)[LD::RS] = lds.R[SIDE][j % 3];
+      int(*KG)[64] = lds.kg[SIDE][j % 3];
+      const CkRow<KIND, NL> ck = ck_next;
+      load_ck<KIND, NL>(ck_next, ck_rows, ck_k, ck_slot(j + 1), SRS, UP, lane);  // next block's checkpoint, a block ahead
+      restore<KIND, NL, RDIR>(S, ck);
+      KG[0][lane] = S.k;
+      int s = 0;  // steps since the checkpoint
+      auto put = [&](int d) __attribute__((always_inline)) {
+        float cs[NL], tx;
+        int kt;
+        S.other_order(cs, tx, kt);
+        write_R<KIND, NL, LD>(RR[d], dump, lane, cs, S.o, tx, kt);
+      };
+      // one step, its row, then (every RN steps, if more rows follow) a renormalisation that opens the next exponent group
+      Emis<NL> eb[BLK];  // full blocks: the emission rows go to registers before the chain starts
+      if (nv == BLK) static_for<0, BLK>([&](auto D) { read_E<NL, LD>(E[decltype(D)::value], lane, eb[decltype(D)::value]); });
+      auto stp = [&](int d) __attribute__((always_inline)) {
+        Emis<NL> e;
+        read_E<NL, LD>(E[d], lane, e);
+        S.step(e);
+      };
+      auto stpb = [&](auto D) __attribute__((always_inline)) { S.step(eb[decltype(D)::value]); };
+      auto after = [&](bool more) __attribute__((always_inline)) {
+        ++s;
+        if (s % RN == 0 && more) {
+          S.template renorm<LV>();
+          KG[s / RN][lane] = S.k;
+        }
+      };
+      if constexpr (SIDE == 0) {
+        // beta recursion downward: R[nv-1] = beta[BLK g + nv] (the checkpoint), then R[d-1] = beta[BLK g + d] after frame d
+        put(nv - 1);
+        if (nv == BLK) {
+          static_for<0, BLK - 1>([&](auto I) {
+            constexpr int d = BLK - 1 - decltype(I)::value;
+            stpb(std::integral_constant<int, d>{}); put(d - 1); after(d > 1);
+          });
+        } else {
+          for (int d = nv - 1; d >= 1; --d) { stp(d); put(d - 1); after(d > 1); }
+        }
+      } else {
+        if constexpr (KIND == 0) {
+          // alpha recursion upward; B's position d holds frame BLK g + nv-1-d; row after each step
+          if (nv == BLK) {
+            static_for<0, BLK>([&](auto I) {
+              constexpr int i = decltype(I)::value;
+              stpb(std::integral_constant<int, BLK - 1 - i>{}); put(BLK - 1 - i); after(i < BLK - 1);
+            });
+          } else {
+            for (int i = 0; i < nv; ++i) { stp(nv - 1 - i); put(nv - 1 - i); after(i < nv - 1); }
+          }
+        } else {
+          put(nv - 1);  // a[BLK g]
+          if (nv == BLK) {
+            static_for<1, BLK>([&](auto I) {
+              constexpr int i = decltype(I)::value;
+              stpb(std::integral_constant<int, BLK - i>{}); put(BLK - 1 - i); after(i < BLK - 1);
+            });
+          } else {
+            for (int i = 1; i < nv; ++i) { stp(nv - i); put(nv - 1 - i); after(i < nv - 1); }
+          }
+        }
+      }
+    }
+    F6_BARRIER();
+  }
+  __syncthreads();
+  F6_STAMP_DUMP(2 + SIDE);
+}
+
+// ------------------------------------------------------------------------------------------------
+// helper wavefront h of NH per side: positions d = h, h + NH, ... of every block (FPH = BLK / NH per block)
+// ------------------------------------------------------------------------------------------------
+template <int KIND, int NL, int NH, int BLK, int VPL, int DIR, int XT>
+__device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, float2 *__restrict__ stats_ws,
+                                           const float *__restrict__ d_loss, float *__restrict__ grad,
+                                           Lds<KIND, NL, NH, BLK, VPL> &lds, const Geo<BLK> &geo, int h, int b, int *flag_ws_dbg = nullptr) {
+  constexpr int V = 256 * VPL;
+  constexpr int FPH = BLK / NH;
+  using LD = Lds<KIND, NL, NH, BLK, VPL>;
+  Rows<KIND, NL, VPL, XT> S;
+  const int lane = threadIdx.x & 63;
+  const int T = p.T;
+  const int len = geo.len;
+  int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  if (ll > p.U) ll = 0;
+  S.init(p, b, lane, ll, d_loss, grad);
+  S.xs = lds.xcopy[DIR * NH + h];
+  S.bins = lds.bins[DIR * NH + h];
+  if (lane == 0) S.xs[V] = 0.f;  // pad slot of the gather copy
+  float2 *stats = stats_ws + (long)b * T;
+  float *dump = lds.dump[4 + DIR * NH + h];
+  const int wave = 4 + DIR * NH + h;
+  F6_STAMP_DECL
+
+  auto write_E = [&](float *row, const Emis<NL> &e) __attribute__((always_inline)) {
+    st_slots<NL>(row + lane * NL, e.y);
+    float *tq = (lane == 0) ? row + LD::UP : dump + lane;
+    *tq = e.bl;
+  };
+  auto fr = [&](int phase, int j, int d) -> int {
+    const int nb = geo.nblocks(phase, DIR);
+    int jj = j < nb ? j : nb - 1;
+    jj = jj < 0 ? 0 : jj;
+    const int g = geo.absblock(phase, DIR, jj);
+    const int nv = geo.nvof(g);
+    int dd = d < nv ? d : nv - 1;
+    int t = geo.frame(DIR, g, dd < 0 ? 0 : dd);
+    t = t < len ? t : len - 1;
+    return t < 0 ? 0 : t;
+  };
+
+  // ================= phase 1: E stage with statistics =================
+  {
+    using SP = P1Split<BLK, NH, NL>;
+    if constexpr (NH == 4) {
+      switch (h) {
+        case 0: estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, dump, lane, wave F6_ST_ARG); break;
+        case 1: estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(1), SP::count(1)>(S, lds, geo, stats, dump, lane, wave F6_ST_ARG); break;
+        case 2: estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(2), SP::count(2)>(S, lds, geo, stats, dump, lane, wave F6_ST_ARG); break;
+        default: estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(3), SP::count(3)>(S, lds, geo, stats, dump, lane, wave F6_ST_ARG); break;
+      }
+    } else {
+      if (h == 0) estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, dump, lane, wave F6_ST_ARG);
+      else estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(1), SP::count(1)>(S, lds, geo, stats, dump, lane, wave F6_ST_ARG);
+    }
+  }
+
+  // ================= meeting point =================
+  __syncthreads();
+  __syncthreads();
+  if (grad == nullptr || lds.feasible == 0) return;  // loss only / flagged
+  F6_STAMP_PHASE2
+
+  // ================= phase 2: E stage (statistics from the record), G stage three blocks behind =================
+  {
+    const int nb = geo.nblocks(2, DIR);
+    if (h == 0 && DIR == 0) S.io.zero_rows(len, T);  // padded frames (base_loss.py:291-296)
+    // Rows of a block are loaded one block ahead of its E stage, exponentiated there (in place) and used again by its G
+    // stage three blocks later: a ring of five register sets addressed by (block mod 5) at COMPILE time.  Wide vocabularies
+    // (four row segments per lane) hold two sets; their G stage re-reads and re-exponentiates its rows.
+    constexpr bool RELOAD = VPL >= 4;
+    constexpr int RING = RELOAD ? 2 : 5;
+    float4 X[RING][FPH][VPL];
+    float4 XG[RELOAD ? FPH : 1][VPL];
+    float2 SG[RING];
+    float2 sgl = make_float2(0.f, 0.f);
+    static_for<0, RING>([&](auto R) {
+      SG[decltype(R)::value] = make_float2(0.f, 0.f);
+      static_for<0, FPH>([&](auto Q) {
+        static_for<0, VPL>([&](auto W) { X[decltype(R)::value][decltype(Q)::value][decltype(W)::value] = make_float4(0.f, 0.f, 0.f, 0.f); });
+      });
+    });
+    float2 st_cur = make_float2(0.f, 0.f), st_next = make_float2(0.f, 0.f);
+    bool massbad = false;
+    if (nb > 0) {
+      static_for<0, FPH>([&](auto Q) { S.io.load_x(X[0][decltype(Q)::value], fr(2, 0, h + NH * decltype(Q)::value)); });
+      st_cur = stats[fr(2, 0, lane)];
+    }
+    auto body = [&](auto R, int it) __attribute__((always_inline)) {
+      constexpr int r = decltype(R)::value;         // = it mod RING
+      constexpr int rn = (r + 1) % RING;            // block it+1 (being loaded)
+      constexpr int rg = (r + 2) % RING;            // block it-3 (G stage; five-set ring only)
+      if constexpr (RELOAD) {
+        static_for<0, FPH>([&](auto Q) { S.io.load_x(XG[decltype(Q)::value], fr(2, it - 3, h + NH * decltype(Q)::value)); });
+        sgl = stats[fr(2, it - 3, lane)];
+      }
+      // ---- E stage (block it) ----
+      const int j = it;
+      SG[r] = st_cur;
+      if (j < nb) {
+        const int g = geo.absblock(2, DIR, j);
+        const int nv = geo.nvof(g);
+        float(*E)[LD::ES] = lds.E[DIR][j % 3];
+        st_next = stats[fr(2, j + 1, lane)];
+        if (__builtin_expect(nv == BLK, 1)) {
+          static_for<0, FPH>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            const int d = h + NH * q;
+            float4 ev[VPL];
+            S.expo(X[r][q], readlane_f(st_cur.x, d), ev);
+            static_for<0, VPL>([&](auto W) {
+              constexpr int w = decltype(W)::value;
+              X[r][q][w] = make_float4(ev[w].x, ev[w].y, ev[w].z, ev[w].w);
+            });
+            Emis<NL> e;
+            S.gather(ev, e);
+            write_E(E[d], e);
+          });
+        } else {
+          for (int d = h; d < nv; d += NH) {
+            float4 xr[VPL], ev[VPL];
+            S.io.load_x(xr, geo.frame(DIR, g, d));
+            const float2 sd = stats[geo.frame(DIR, g, d)];
+            S.expo(xr, sd.x, ev);
+            Emis<NL> e;
+            S.gather(ev, e);
+            write_E(E[d], e);
+          }
+        }
+#ifndef CTC_F6_NOLOAD2  // (experiment: no second read of the logits -- results are wrong)
+        static_for<0, FPH>([&](auto Q) { S.io.load_x(X[rn][decltype(Q)::value], fr(2, j + 1, h + NH * decltype(Q)::value)); });
+#endif
+        st_cur = st_next;
+      }
+      // ---- G stage (block it-3): posterior scatter + gradient rows ----
+      const int gj = it - 3;
+      if (gj >= 0 && gj < nb) {
+        const int g = geo.absblock(2, DIR, gj);
+        const int nv = geo.nvof(g);
+        const float(*SR)[LD::RS] = lds.R[DIR][gj % 3];
+        auto read_S = [&](int d, float &qb, float (&qt)[NL]) __attribute__((always_inline)) {
+          const float *srow = SR[d] + 2 * lane * NL;
+          if constexpr (NL == 1) { const float2 t = *reinterpret_cast<const float2 *>(srow); qb = t.x; qt[0] = t.y; }
+          else if constexpr (NL == 2) { const float4 t = *reinterpret_cast<const float4 *>(srow); qb = t.x; qt[0] = t.y; qt[1] = t.z; }
+          else { const float4 t = *reinterpret_cast<const float4 *>(srow); qb = t.x; qt[0] = t.y; qt[1] = t.z; qt[2] = t.w; qt[3] = srow[4]; }
+        };
+        if (__builtin_expect(nv == BLK, 1)) {
+          float qb[2 * FPH], qt[FPH][NL];  // qb[FPH + q]: total posterior mass of the frame (D6)
+          static_for<0, FPH>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            read_S(h + NH * q, qb[q], qt[q]);
+            qb[FPH + q] = qb[q];
+#pragma unroll
+            for (int jj = 0; jj < NL; ++jj) qb[FPH + q] += qt[q][jj];
+          });
+#ifdef CTC_F6_DEBUG2
+          if (DIR == 0 && gj == 0 && h == 1 && NL == 2) {  // what helper 1 of side A reads for position d = 1 of the first block
+            int *dbg = flag_ws_dbg + p.B + (long)b * 2048 + 1024;
+            dbg[lane] = __float_as_int(qb[0]); dbg[64 + lane] = __float_as_int(qt[0][0]); dbg[128 + lane] = __float_as_int(qt[0][NL - 1]);
+          }
+#endif
+          dpp_sum_n<2 * FPH>(qb);  // blank posteriors and total masses of the FPH frames, one batched wave reduction
+          static_for<0, FPH>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            const int d = h + NH * q;
+            const float qbs = readlane_f(qb[q], 63);
+            massbad |= !(fabsf(readlane_f(qb[FPH + q], 63) - 1073741824.0f) < 1073741824.0f * 1e-4f);
+            if constexpr (RELOAD) {
+              float4 ev[VPL];
+              S.expo(XG[q], readlane_f(sgl.x, d), ev);
+              S.grad_row(geo.frame(DIR, g, d), qbs, qt[q], ev, readlane_f(sgl.y, d));
+            } else {
+              S.grad_row(geo.frame(DIR, g, d), qbs, qt[q], X[rg][q], readlane_f(SG[rg].y, d));
+            }
+          });
+        } else {
+          for (int d = h; d < nv; d += NH) {
+            float4 xr[VPL], ev[VPL];
+            S.io.load_x(xr, geo.frame(DIR, g, d));
+            const float2 sd = stats[geo.frame(DIR, g, d)];
+            S.expo(xr, sd.x, ev);
+            float qb, qt[NL];
+            read_S(d, qb, qt);
+            float tot = qb;
+#pragma unroll
+            for (int jj = 0; jj < NL; ++jj) tot += qt[jj];
+            qb = wave_sum_dpp(qb);
+            massbad |= !(fabsf(wave_sum_dpp(tot) - 1073741824.0f) < 1073741824.0f * 1e-4f);
+            S.grad_row(geo.frame(DIR, g, d), qb, qt, ev, sd.y);
+          }
+        }
+      }
+      F6_BARRIER();
+    };
+    for (int it0 = 0; it0 <= geo.NB + 2; it0 += RING) {
+      static_for<0, RING>([&](auto R) {
+        if (it0 + decltype(R)::value <= geo.NB + 2) body(R, it0 + decltype(R)::value);
+      });
+    }
+    if (massbad && lane == 0) atomicOr(&lds.flag, 64);  // D6
+  }
+  __syncthreads();
+  F6_STAMP_DUMP(wave);
+}
+
+// Wavefront roles: 0 main A, 1 main B, 2 recompute for A, 3 recompute for B, then NH helpers of A, NH helpers of B.
+template <int KIND, int NL, int NH, int BLK, int VPL, int XT>
+__global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused6_kernel(Problem p, Layout L, float *__restrict__ alpha_ws,
+                                                                    float *__restrict__ beta_ws, int *__restrict__ kexp_ws,
+                                                                    double *__restrict__ logp_ws,
+                                                                    float2 *__restrict__ stats_ws,
+                                                                    float *__restrict__ loss,
+                                                                    const float *__restrict__ d_loss,
+                                                                    float *__restrict__ grad, int *__restrict__ flag_ws,
+                                                                    const int *__restrict__ perm) {
+  __shared__ __attribute__((aligned(16))) Lds<KIND, NL, NH, BLK, VPL> lds;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = perm ? perm[blockIdx.x] : (int)blockIdx.x;
+  Geo<BLK> geo;
+  geo.init(clampi(p.logit_length[b], 0, p.T));
+  if (threadIdx.x == 0) { lds.flag = 0; lds.feasible = 0; }
+  if (threadIdx.x < Lds<KIND, NL, NH, BLK, VPL>::NW) lds.l2s[threadIdx.x] = 0.0;
+  __syncthreads();
+  if (w == 0) {
+    __builtin_amdgcn_s_setprio(3);
+    run_main<KIND, NL, NH, BLK, VPL, 0>(p, L, alpha_ws, beta_ws, kexp_ws, logp_ws, loss, flag_ws, lds, geo, grad != nullptr, b);
+  } else if (w == 1) {
+    __builtin_amdgcn_s_setprio(3);
+    run_main<KIND, NL, NH, BLK, VPL, 1>(p, L, alpha_ws, beta_ws, kexp_ws, logp_ws, loss, flag_ws, lds, geo, grad != nullptr, b);
+  } else if (w == 2) {
+    __builtin_amdgcn_s_setprio(2);
+    run_recompute<KIND, NL, NH, BLK, VPL, 0, XT>(p, L, alpha_ws, beta_ws, kexp_ws, stats_ws, lds, geo, grad != nullptr, b, flag_ws);
+  } else if (w == 3) {
+    __builtin_amdgcn_s_setprio(2);
+    run_recompute<KIND, NL, NH, BLK, VPL, 1, XT>(p, L, alpha_ws, beta_ws, kexp_ws, stats_ws, lds, geo, grad != nullptr, b, flag_ws);
+  } else if (w < 4 + NH) {
+    run_helper<KIND, NL, NH, BLK, VPL, 0, XT>(p, L, stats_ws, d_loss, grad, lds, geo, w - 4, b, flag_ws);
+  } else {
+    run_helper<KIND, NL, NH, BLK, VPL, 1, XT>(p, L, stats_ws, d_loss, grad, lds, geo, w - 4 - NH, b, flag_ws);
+  }
+}
+
+}  // namespace fused6
+
+template <int NL, int NH, int BLK, int VPL>
+static hipError_t launch6(const Problem &p, const Layout &L, float *a, float *b, int *kexp, double *lp, float2 *stats, float *loss,
+                          const float *d_loss, float *grad, int *flags, const int *perm, hipStream_t st) {
+  static_assert(sizeof(fused6::Lds<CTC_FUSED_KIND, NL, NH, BLK, VPL>) <= 160 * 1024, "LDS budget of one CU");
+  const bool plain = p.xdtype == 0 && p.V == 256 * VPL && p.xst == p.V && p.gst == p.V;
+  const dim3 grid(p.B), block(64 * (4 + 2 * NH));
+  if (plain)
+    hipLaunchKernelGGL((fused6::fused6_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 0>), grid, block, 0, st, p, L, a, b, kexp, lp, stats, loss,
+                       d_loss, grad, flags, perm);
+  else if (p.xdtype == 0 && ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0)
+    hipLaunchKernelGGL((fused6::fused6_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 1>), grid, block, 0, st, p, L, a, b, kexp, lp, stats, loss,
+                       d_loss, grad, flags, perm);
+  else if (p.xdtype == 0)
+    hipLaunchKernelGGL((fused6::fused6_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 3>), grid, block, 0, st, p, L, a, b, kexp, lp, stats, loss,
+                       d_loss, grad, flags, perm);
+  else
+    hipLaunchKernelGGL((fused6::fused6_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 2>), grid, block, 0, st, p, L, a, b, kexp, lp, stats, loss,
+                       d_loss, grad, flags, perm);
+  return hipGetLastError();
+}
+
+// One translation unit per (lattice kind, label positions per lane): -DCTC_FUSED_KIND=0|1 -DCTC_FUSED6_NL=1|2|4.
+// Exported: run_fused6_<kind>_nl<NL>.  Writes flags[b] != 0 for every utterance the caller has to redo in the log domain.
+#ifndef CTC_FUSED6_NL
+#error "compile with -DCTC_FUSED6_NL=1, 2 or 4"
+#endif
+#define CTC_F6_CAT2(a, b, c) a##b##c
+#define CTC_F6_CAT(a, b, c) CTC_F6_CAT2(a, b, c)
+#if CTC_FUSED_KIND == 0
+#define CTC_F6_ENTRY CTC_F6_CAT(run_fused6_classic, _nl, CTC_FUSED6_NL)
+#else
+#define CTC_F6_ENTRY CTC_F6_CAT(run_fused6_simplified, _nl, CTC_FUSED6_NL)
+#endif
+hipError_t run_order(const Problem &p, const Layout &L, char *ws, hipStream_t st);  // ctc_kernels.hip
+
+hipError_t CTC_F6_ENTRY(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad,
+                        hipStream_t st) {
+  float *alpha = reinterpret_cast<float *>(ws + L.off_alpha);
+  float *beta = reinterpret_cast<float *>(ws + L.off_beta);
+  double *logp = reinterpret_cast<double *>(ws + L.off_logp);
+  float2 *stats = reinterpret_cast<float2 *>(ws + L.off_emis);  // the emission region of the v1 pipeline is free here
+  int *kexp = reinterpret_cast<int *>(ws + L.off_kexp);
+  int *flags = reinterpret_cast<int *>(ws + L.off_flags);
+  if (L.NL != CTC_FUSED6_NL) return hipErrorInvalidValue;
+  // more utterances than CUs: longest first (one small kernel; skipped for batches that fit the chip in one go)
+  const int *perm = nullptr;
+  if (p.B > 256 && p.B <= 8192) {
+    hipError_t e = run_order(p, L, ws, st);
+    if (e != hipSuccess) return e;
+    perm = reinterpret_cast<const int *>(ws + L.off_perm);
+  }
+#if CTC_FUSED6_NL == 4
+  return p.V <= 256 ? launch6<4, 2, 6, 1>(p, L, alpha, beta, kexp, logp, stats, loss, d_loss, grad, flags, perm, st)
+                    : launch6<4, 2, 6, 2>(p, L, alpha, beta, kexp, logp, stats, loss, d_loss, grad, flags, perm, st);
+#else
+  return p.V <= 256   ? launch6<CTC_FUSED6_NL, 4, 12, 1>(p, L, alpha, beta, kexp, logp, stats, loss, d_loss, grad, flags, perm, st)
+         : p.V <= 512 ? launch6<CTC_FUSED6_NL, 2, 6, 2>(p, L, alpha, beta, kexp, logp, stats, loss, d_loss, grad, flags, perm, st)
+                      : launch6<CTC_FUSED6_NL, 2, 6, 4>(p, L, alpha, beta, kexp, logp, stats, loss, d_loss, grad, flags, perm, st);
+#endif
+}
+
+}  // namespace ctc

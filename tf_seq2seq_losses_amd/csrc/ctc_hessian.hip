@@ -20,6 +20,7 @@
 #include "ctc_fused_common.h"
 
 namespace ctc {
+extern int g_force_hessian_slab;  // ctc_capi.hip
 
 using namespace ctc::fused;
 
@@ -791,9 +792,8 @@ hipError_t run_hessian(const Problem &p, const Layout &L, char *ws, const float 
   char *ex = ws + L.off_extra + al((size_t)p.B * p.T * p.V * sizeof(float));
   int *order = reinterpret_cast<int *>(ex);
   int *npres = reinterpret_cast<int *>(ex + al((size_t)p.B * p.V * sizeof(int)));
-  // short labels: two slabs per wavefront (CTC_AMD_HESSIAN=slab forces the one-slab kernel; the parity tests run both)
-  const char *force = getenv("CTC_AMD_HESSIAN");
-  if (p.U <= 32 && (size_t)2 * (p.V + 4 + 8 * p.V) * 4 <= 64 * 1024 && !(force && force[0] == 's')) {
+  // short labels: two slabs per wavefront (ctc_amd_debug_override("hessian", "slab") forces the one-slab kernel; the parity tests run both)
+  if (p.U <= 32 && (size_t)2 * (p.V + 4 + 8 * p.V) * 4 <= 64 * 1024 && !g_force_hessian_slab) {
     unsigned long long *dbg = reinterpret_cast<unsigned long long *>(ws + L.off_dummy);  // diagnostic builds only
     return p.kind == 0 ? launch_pair<0>(p, L, emis, alpha, beta, logp, g_lp, order, npres, hess, dbg, st)
                        : launch_pair<1>(p, L, emis, alpha, beta, logp, g_lp, order, npres, hess, dbg, st);

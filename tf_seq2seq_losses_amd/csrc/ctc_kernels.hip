@@ -630,4 +630,28 @@ hipError_t run_convert(const Problem &p, const Layout &L, char *ws, float *alpha
   return hipGetLastError();
 }
 
+// perm[rank] = utterance with the rank-th longest logit_length (ties by index): B <= 8192, one thread per utterance; the
+// lengths are staged in LDS once per workgroup (a per-thread loop over global memory took ~30 us at B = 512)
+static __global__ __launch_bounds__(256) void order_kernel(const int *__restrict__ logit_length, int B, int T,
+                                                           int *__restrict__ perm) {
+  __shared__ int len_s[8192];
+  for (int j = threadIdx.x; j < B; j += 256) len_s[j] = (logit_length[j] < 0 ? 0 : (logit_length[j] > T ? T : logit_length[j]));
+  __syncthreads();
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const int mine = len_s[b];
+  int rank = 0;
+  for (int j = 0; j < B; ++j) {
+    const int other = len_s[j];
+    rank += (other > mine) || (other == mine && j < b);
+  }
+  perm[rank] = b;
+}
+
+hipError_t run_order(const Problem &p, const Layout &L, char *ws, hipStream_t st) {
+  int *perm = reinterpret_cast<int *>(ws + L.off_perm);
+  hipLaunchKernelGGL(order_kernel, dim3((p.B + 255) / 256), dim3(256), 0, st, p.logit_length, p.B, p.T, perm);
+  return hipGetLastError();
+}
+
 }  // namespace ctc

@@ -18,7 +18,6 @@ All arithmetic is done by the HIP kernels behind the C ABI (include/ctc_amd.h); 
 """
 from __future__ import annotations
 
-import os
 from functools import cached_property
 from typing import Union
 
@@ -62,6 +61,9 @@ def _verify_inputs(labels, x, label_length, logit_length):
 # --------------------------------------------------------------------------------------------------
 # autograd wiring (base_loss.py:140-184)
 # --------------------------------------------------------------------------------------------------
+HVP_DENSE = False  # diagnostic: second-order autograd through a materialised [B,T,V,T,V] Hessian, as the reference does
+
+
 class _HessianContraction(torch.autograd.Function):
     """gradient_fn.backprop (base_loss.py:167-173): out[b,t,k] = sum_{t2,k2} v[b,t2,k2] H[b,t,k,t2,k2].
     Its own backward is the third derivative, which the reference refuses (base_loss.py:179-182)."""
@@ -69,8 +71,8 @@ class _HessianContraction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, v, kind, wrt, prep):
         # the reference contracts a materialised [B,T,V,T,V] Hessian here; the tangent-mode kernel (ctc_hvp.hip) gives the
-        # same product in O(T*L) memory.  CTC_AMD_HVP=dense keeps the materialised route (parity tests compare both).
-        if os.environ.get("CTC_AMD_HVP", "") == "dense":
+        # same product in O(T*L) memory.  HVP_DENSE keeps the materialised route (parity tests compare both).
+        if HVP_DENSE:
             _, _, hess = ops.hessian(kind, wrt, prep, want_grad=False)
             return torch.einsum("btkuj,buj->btk", hess, v.float()).to(x.dtype)
         return ops.hvp(kind, wrt, prep, v)[2].to(x.dtype)
