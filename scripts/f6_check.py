@@ -126,6 +126,58 @@ if __name__ == "__main__":
         run("classic", 128, 1000, 128, 256, seed=2, ncheck=2, reps=50)
         run("classic", 192, 1000, 128, 256, seed=2, ncheck=2, reps=50)
         run("classic", 256, 1000, 128, 256, seed=2, ncheck=2, reps=50)
+    if which == "sweepcase":
+        T, U, V, B = (int(a) for a in sys.argv[2:6])
+        kind = sys.argv[6] if len(sys.argv) > 6 else "classic"
+        rng = np.random.default_rng(T * 1000 + U * 10 + V)
+        z = rng.standard_normal((B, T, V))
+        sc = rng.choice([0.5, 1.0, 4.0])
+        logits = (z * sc).astype(np.float32)
+        labels = rng.integers(1, V, (B, max(U, 1))).astype(np.int32)
+        if U >= 4:
+            labels[0, : U // 2] = labels[0, 0]
+        ll = rng.integers(0, U + 1, B).astype(np.int32)
+        tl = rng.integers(0, T + 1, B).astype(np.int32)
+        ll[0], tl[0] = U, T
+        print("scale", sc, "ll", ll.tolist(), "tl", tl.tolist())
+        k = ops.KINDS[kind]
+        p = ops.Prepared(torch.from_numpy(labels).to(dev), torch.from_numpy(logits).to(dev), torch.from_numpy(ll).to(dev),
+                         torch.from_numpy(tl).to(dev), 0, U=U)
+        rl, rg = C.loss_grad(kind, labels, logits, ll, tl, 0)
+        loss, grad = ops.loss_grad(k, _lib.WRT_LOGITS, p, True)
+        torch.cuda.synchronize()
+        e0 = np.abs(grad.cpu().numpy() - rg).max(axis=(1, 2))
+        loss_only, _ = ops.loss_grad(k, _lib.WRT_LOGITS, p, False)
+        torch.cuda.synchronize()
+        e1 = np.abs(grad.cpu().numpy() - rg).max(axis=(1, 2))
+        print("default workspace path: per-utterance grad err right after the call", e0.tolist(), "after a loss-only call", e1.tolist(),
+              "loss", loss.cpu().numpy().tolist(), "loss-only", loss_only.cpu().numpy().tolist())
+        for pipe in ("", "fused5", "v1"):
+            _lib.debug_override("pipeline", pipe)
+            nws = _lib.workspace_bytes(_lib.WS_LOSS_GRAD, k, B, T, V, U)
+            for fill in ("zeros", "ones", "random"):
+                ws = (torch.zeros(nws, dtype=torch.uint8, device=dev) if fill == "zeros" else
+                      torch.full((nws,), 255, dtype=torch.uint8, device=dev) if fill == "ones" else
+                      torch.randint(0, 256, (nws,), dtype=torch.uint8, device=dev))
+                loss, grad = ops.loss_grad(k, _lib.WRT_LOGITS, p, True, workspace=ws)
+                torch.cuda.synchronize()
+                print(f"   workspace filled with {fill}: max grad err {np.abs(grad.cpu().numpy() - rg).max():.3e}")
+            gn = grad.cpu().numpy()
+            err = np.abs(gn - rg).max(axis=(1, 2))
+            fl = flags_of(ws, k, B, T, V, U) if pipe == "" else None
+            print(f"pipeline {pipe or 'default'}: per-utterance grad err {err.tolist()} loss {loss.cpu().numpy().tolist()} ref {rl.tolist()} flags {None if fl is None else [hex(int(f)) for f in fl]}")
+            if pipe == "":
+                b0 = int(np.argmax(err))
+                e = np.abs(gn[b0] - rg[b0])
+                bad = np.nonzero(e.max(axis=1) > 1e-4)[0]
+                print("   worst utterance", b0, "frames with err > 1e-4:", bad.tolist(), "max |row sum of grad|:", np.abs(gn[b0].sum(axis=1)).max())
+                for t in bad[:4]:
+                    ks = np.argsort(-e[t])[:4]
+                    print(f"     t={t}: row sum {gn[b0, t].sum():.3e}; worst tokens (k, got, want):", [(int(kk), float(gn[b0, t, kk]), float(rg[b0, t, kk])) for kk in ks])
+        _lib.debug_override("pipeline", "")
+    if which == "scal":
+        for (U, V) in ((128, 256), (64, 256), (128, 128), (64, 128), (32, 64), (128, 252), (20, 256)):
+            run("classic", 256, 1000, U, V, seed=2, ncheck=1, reps=50)
     if which == "nsc":
         run("classic", 256, 1000, 128, 256, seed=int(os.environ.get("F6_SEED", "2")), ncheck=2, reps=50)
     if which == "ns":

@@ -30,7 +30,9 @@
 //       1 by more than 1e-4.  Flushing only ever removes mass, and mass that one chain loses at (t1, s1) is still carried
 //       by the other chain on the far side of t1, so sum_s alpha_t beta_t stops being the same for all t: every frame is
 //       checked against P from the meeting point.  A loss below 1e-4 of P is below the tolerance of the gradient.
-//   D3-D5 (calls WITHOUT a gradient have no phase 2 to check the mass in; they fall back on conservative local signs)
+//   D5  a lane's alpha and beta exponents exceed log2 P by more than 90 in the posterior: mantissa products that underflow
+//       would no longer be negligible (see KK_MAX)
+//   D3, D4 (calls WITHOUT a gradient have no phase 2 to check the mass in; they fall back on conservative local signs)
 //       D3 a renormalisation scales a lane's own live values down by more than 2^-64; D4 a lane's maximum decays by more
 //       than 2^-64 within one renormalisation period, or a live lane goes to zero
 //
@@ -51,8 +53,10 @@ constexpr int DEAD = -(1 << 24);  // exponent of a lane whose mantissas are all 
 constexpr int GAP = 16;           // a dead lane adopts its upstream neighbour's exponent minus GAP
 constexpr int DOWN_MAX = 64;      // D3
 constexpr int DECAY_MAX = 64;     // D4
-constexpr int KK_MAX = 80;        // posterior scale clamp: a lane's alpha and beta exponents above log2 P by more than this
-                                  // (their true product is <= P) means lost mass -- D6 sees it
+constexpr int KK_MAX = 90;        // D5: posterior scale 2^KK_MAX at most.  The posterior of a state is (alpha mantissa)(beta
+                                  // mantissa) 2^(kA + kB - log2 P); the mantissa PRODUCT underflows below 2^-126, which is harmless
+                                  // while the scale stays below 2^90 (the lost term is < 2^-5 units of 2^-30) and fatal beyond --
+                                  // sharp logits on a nearly forced alignment get there in the frames just before a renormalisation
 constexpr float EMIS_MIN = 7.52316384526264e-37f;  // 2^-120 (D2)
 
 #ifdef CTC_F6_STAMPS
@@ -98,9 +102,7 @@ template <int BLK, int NL>
 struct Cad {
   static constexpr int RN = (BLK % 4 == 0) ? 4 : 3;
   static constexpr int NG = BLK / RN;            // exponent groups of the rows of one block
-  // adoption levels: lanes the front crosses in one period, + 1 because the recompute chain shifts its row into the other
-  // direction's slot order right after a step, which reads the front one lane further than the next step would
-  static constexpr int LV = (RN + NL - 1) / NL + 1;
+  static constexpr int LV = (RN + NL - 1) / NL;  // adoption levels: lanes the lattice front can cross in one period
   static_assert(BLK % RN == 0, "block length must be a multiple of the renormalisation period");
 };
 
@@ -108,14 +110,15 @@ template <int KIND, int NL, int NH, int BLK, int VPL>
 struct Lds {
   static constexpr int V = 256 * VPL, UP = 64 * NL;
   static constexpr int ES = UP + 4;      // E row: y[UP] (exp(x_label - rowmax)), then e_blank
-  static constexpr int RS = 2 * UP + 8;  // R row (recompute chain): the other direction's mantissas in the main chain's slot order,
-                                         // tail (state outside the slot range, its exponent); S row (main chain, in place): per lane
-                                         // 2 NL floats (blank posterior of the lane, token posteriors) in units of 2^-30
+  static constexpr int RS = 2 * UP + 8;  // R row (recompute chain): its NATIVE state -- pairs (c, o) per slot, tail (cx, kx); the main
+                                         // chain shifts it into its own slot order when it reads it.  S row (main chain, in place):
+                                         // per lane 2 NL floats of posterior parts (see run_main)
   static constexpr int NG = Cad<BLK, NL>::NG;
   static constexpr int NW = 4 + 2 * NH;
   float E[2][3][BLK][ES];   // [side][block % 3]
   float R[2][3][BLK][RS];   // [side][block % 3]
   int kg[2][3][NG][64];     // per-lane exponents of the R rows, one set per renormalisation group
+  float kl[2][3][BLK][64];  // per-lane posterior scale of the S rows' raw parts (written by the main chain with every S row)
   float xcopy[2 * NH][V + 4];
   float xcopy_r[2][V + 4];  // row copies of the recompute waves (E stage of phase 1)
   float bins[2 * NH][V + 4];
@@ -203,29 +206,28 @@ __device__ __forceinline__ void read_E(const float *row, int lane, Emis<NL> &e) 
   e.bl = row[LDt::UP];  // same address in every lane: LDS broadcast
 }
 
-// one lattice row of the OTHER direction in this chain's slot order (R row)
+// one lattice row of the OTHER direction as that direction's chain holds it (R row): c[j] / o[j] per slot, boundary state cx
+// with its exponent kx.  Pair layout for both kinds (simplified: second element unused): the R data of a lane then occupies
+// exactly the 2 NL floats its S row entry overwrites in place.  With a packed simplified row, lane L's S entry would
+// overlap the R data of lanes 2L and 2L+1 -- and nothing orders one lane's store against ANOTHER lane's earlier load
+// (the compiler hoisted a piece of the store above the load; per thread the two never alias).
 template <int KIND, int NL>
 struct RRow {
-  float a[NL];  // classic: closed part / simplified: the state
-  float b[NL];  // classic: open part
-  float tx;     // state outside the slot range
-  int kt;       // its exponent
+  float c[NL], o[NL];
+  float cx;
+  int kx;
 };
-// Both kinds use the pair layout (simplified: second element unused): the R data of a lane then occupies exactly the 2 NL
-// floats its S row entry overwrites in place.  With a packed simplified row, lane L's S entry would overlap the R data of
-// lanes 2L and 2L+1 -- and nothing orders one lane's store against ANOTHER lane's earlier load (the compiler hoisted a
-// piece of the store above the load; per thread the two never alias).
 template <int KIND, int NL, class LDt>
 __device__ __forceinline__ void read_R(const float *row, int lane, RRow<KIND, NL> &r) {
-  ld_pairs<NL>(row + 2 * lane * NL, r.a, r.b);
+  ld_pairs<NL>(row + 2 * lane * NL, r.c, r.o);
   const float2 t = *reinterpret_cast<const float2 *>(row + 2 * LDt::UP);
-  r.tx = t.x; r.kt = __float_as_int(t.y);
+  r.cx = t.x; r.kx = __float_as_int(t.y);
 }
 template <int KIND, int NL, class LDt>
-__device__ __forceinline__ void write_R(float *row, float *dump, int lane, const float (&a)[NL], const float (&b)[NL], float tx, int kt) {
-  st_pairs<NL>(row + 2 * lane * NL, a, b);
+__device__ __forceinline__ void write_R(float *row, float *dump, int lane, const float (&c)[NL], const float (&o)[NL], float cx, int kx) {
+  st_pairs<NL>(row + 2 * lane * NL, c, o);
   float *tq = (lane == 0) ? row + 2 * LDt::UP : dump + (lane & 31) * 2;  // lanes > 0 write a sink
-  *reinterpret_cast<float2 *>(tq) = make_float2(tx, __int_as_float(kt));
+  *reinterpret_cast<float2 *>(tq) = make_float2(cx, __int_as_float(kx));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -256,6 +258,7 @@ struct Chain {
       o[j] = 0.f;
     }
     cx = 0.f; k = DEAD; kx = DEAD; dk = 0; flag = 0;
+    relevant = lane * NL <= ll;  // the lane holds a label position that can carry mass (lanes beyond the label stay empty for good)
   }
 
   // starting state: alpha[0] = delta(closed(l=0)) / beta[len] = delta(closed(l=ll)) + delta(open(l=ll))
@@ -346,10 +349,18 @@ struct Chain {
     const bool xlive = cx > 0.f;
     const int ex = xlive ? frexp_e(cx) + kx : DEAD;
     int kn = e_own;
-#pragma unroll
-    for (int lv = 0; lv < LV; ++lv) {
+    // one level always (a lane far below its upstream neighbour is lifted to its exponent - GAP); the further levels only
+    // serve lanes without mass, which need an exponent before the front reaches them (wave-uniform branch)
+    {
       const int nb = (DIR == 0) ? from_prev_lane_i(kn, ex) : from_next_lane_i(kn, ex);
       kn = imax(kn, nb - GAP);
+    }
+    if (__builtin_amdgcn_ballot_w64(!live && relevant) != 0) {
+#pragma unroll
+      for (int lv = 1; lv < LV; ++lv) {
+        const int nb = (DIR == 0) ? from_prev_lane_i(kn, ex) : from_next_lane_i(kn, ex);
+        kn = imax(kn, nb - GAP);
+      }
     }
     kn = imax(kn, DEAD);
     const int d = k - kn;
@@ -372,6 +383,7 @@ struct Chain {
     alive = live;
   }
   bool alive = false;  // the lane had mass at its last renormalisation
+  bool relevant = true;
 #ifdef CTC_F6_DEBUG
   int cnt = 0, dbg0 = 0, dbg1 = 0, dbg2 = 0;
   float mlast = 0.f;
@@ -384,24 +396,6 @@ struct Chain {
     return f;
   }
 
-  // the state in the slot order of the OTHER direction (what that direction's main chain multiplies with):
-  //   DIR 1 (B-native) -> A order: slot i = (state_c(l=i+1) [, open(l=i+1)]), outside = state_c(l=0)
-  //   DIR 0 (A-native) -> B order: slot i = (state_c(l=i)   [, open(l=i+1)]), outside = state_c(l=UP)
-  __device__ __forceinline__ void other_order(float (&cs)[NL], float &tx, int &kt) const {
-    if constexpr (DIR == 0) {
-#pragma unroll
-      for (int j = NL - 1; j > 0; --j) cs[j] = c[j - 1];
-      cs[0] = ldexp_f(from_prev_lane(c[NL - 1], cx), dk);
-      tx = readlane_f(c[NL - 1], 63);
-      kt = readlane_i(k, 63);
-    } else {
-#pragma unroll
-      for (int j = 0; j < NL - 1; ++j) cs[j] = c[j + 1];
-      cs[NL - 1] = ldexp_f(from_next_lane(c[0], cx), dk);
-      tx = readlane_f(c[0], 0);
-      kt = readlane_i(k, 0);
-    }
-  }
 };
 
 // checkpoint row in HBM: the chain's NATIVE state.  rows: [slot][SRS] floats (pairs (c, o) for classic, c for simplified,
@@ -853,70 +847,90 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
           const int s = (KIND == 0 && DIR == 1) ? nv - d : nv - 1 - d;
           return (s > 0 ? s - 1 : 0) / RN;
         };
-        int q = -1, kR = DEAD;
-        float KL = 0.f;
+        // The R row holds the other direction's state in ITS slot order and lane exponents (group q); this chain needs it
+        // one label position over, so one value per lane comes from the neighbour lane and carries that lane's exponent:
+        // products with it ("shifted" parts) are scaled here, with their own scale KS; the others ("aligned") stay raw and
+        // the helper multiplies them by the lane's scale KL (lds.kl), off the sequential chain.
+        // S row entry per lane (in place of the R row, a region of 2 NL floats):
+        //   NL >= 2: [aligned blank part (raw), token parts[NL] (raw; simplified: the shifted slot scaled), shifted blank part (scaled)]
+        //   NL = 1 : [token part, shifted blank part]
+        // row tail .x (where the R row had cx): posterior of the boundary state, scaled (uniform).
+        float(*KLr)[64] = lds.kl[DIR][j % 3];
+        int q = -1, kR = DEAD, ks = DEAD, k0r = DEAD;
+        float KL = 0.f, KS = 0.f, K0 = 0.f;
         auto setK = [&]() __attribute__((always_inline)) {
-          const int kk = S.k + kR - lp_int;
-          kflag |= (kk > KK_MAX);
-          KL = ldexp_f(cf30, imin(kk, KK_MAX));
+          const int ka = S.k + kR - lp_int, kb = S.k + ks - lp_int, kc = S.kx + k0r - lp_int;
+          kflag |= (imax(ka, imax(kb, kc)) > KK_MAX);  // D5
+          KL = ldexp_f(cf30, imin(ka, KK_MAX));
+          KS = ldexp_f(cf30, imin(kb, KK_MAX));
+          K0 = ldexp_f(cf30, imin(kc, KK_MAX));
         };
         auto one = [&](int d, int qd, bool ren, const Emis<NL> &e, const RRow<KIND, NL> &r, int kRq) __attribute__((always_inline)) {
-          if (qd != q) { q = qd; kR = kRq; setK(); }
-          float qb, qt[NL], p0;
+          if (qd != q) {  // new exponent group of the rows (the boundary exponent r.kx is constant inside a group as well)
+            q = qd; kR = kRq;
+            ks = (DIR == 0) ? from_next_lane_i(kR, r.kx) : from_prev_lane_i(kR, r.kx);
+            k0r = readlane_i(kR, DIR == 0 ? 0 : 63);
+            setK();
+          }
+          // the value one label position over: from the next lane for A (needs l = i+1 of a row that holds l = i), from the
+          // previous lane for B; and the row's state at this chain's boundary position (l = 0 for A, l = UP for B)
+          const float rs = (DIR == 0) ? from_next_lane(r.c[0], r.cx) : from_prev_lane(r.c[NL - 1], r.cx);
+          const float r0 = (DIR == 0) ? readlane_f(r.c[0], 0) : readlane_f(r.c[NL - 1], 63);
+          float qal = 0.f, tok[NL], qsh, p0;
           if constexpr (KIND == 0) {
             if constexpr (DIR == 0) S.step(e);  // A: posterior of frame t from alpha[t+1], beta[t+1]
-            // (A renormalises after the products below; its exponent is still the one KL was built from.  Products first,
-            // then the scale: a mantissa product may underflow -- by then it is below 2^-16 units -- but never overflows)
-            qb = 0.f;
+            // (A renormalises after the products below; its exponent is still the one the scales were built from.  A mantissa
+            // product may underflow -- by then it is below 2^-16 units after scaling -- but never overflows)
 #pragma unroll
-            for (int jj = 0; jj < NL; ++jj) { qb += S.c[jj] * r.a[jj]; qt[jj] = (S.o[jj] * r.b[jj]) * KL; }
-            qb *= KL;
-            p0 = S.cx * r.tx;
+            for (int jj = 0; jj < NL; ++jj) tok[jj] = S.o[jj] * r.o[jj];
+            if constexpr (DIR == 0) {
+#pragma unroll
+              for (int jj = 0; jj < NL - 1; ++jj) qal += S.c[jj] * r.c[jj + 1];
+              qsh = (S.c[NL - 1] * rs) * KS;
+            } else {
+#pragma unroll
+              for (int jj = 1; jj < NL; ++jj) qal += S.c[jj] * r.c[jj - 1];
+              qsh = (S.c[0] * rs) * KS;
+            }
+            p0 = S.cx * r0;
           } else if constexpr (DIR == 0) {
             const float pin0 = ldexp_f(from_prev_lane(S.c[NL - 1], S.cx), S.dk);
-            qb = 0.f;
 #pragma unroll
             for (int jj = 0; jj < NL; ++jj) {
               const float pin = (jj == 0) ? pin0 : S.c[jj - 1];
-              qb += S.c[jj] * r.a[jj];
-              qt[jj] = ((pin * e.y[jj]) * r.a[jj]) * KL;
+              const float rn = (jj < NL - 1) ? r.c[(jj + 1) % NL] : rs;  // b(l = i+1)
+              tok[jj] = (pin * e.y[jj]) * rn;
+              if (jj < NL - 1) qal += S.c[jj] * rn;
             }
-            qb *= e.bl * KL;
-            p0 = S.cx * e.bl * r.tx;
+            qal *= e.bl;
+            qsh = ((S.c[NL - 1] * rs) * e.bl) * KS;
+            tok[NL - 1] *= KS;
+            p0 = S.cx * e.bl * r0;
           } else {
             const float nin = ldexp_f(from_next_lane(S.c[0], S.cx), S.dk);
-            qb = 0.f;
 #pragma unroll
             for (int jj = 0; jj < NL; ++jj) {
-              const float nx = (jj == NL - 1) ? nin : S.c[jj + 1];
-              qb += S.c[jj] * r.a[jj];
-              qt[jj] = ((nx * e.y[jj]) * r.a[jj]) * KL;
+              const float nx = (jj == NL - 1) ? nin : S.c[(jj + 1) % NL];
+              const float rp = (jj > 0) ? r.c[(jj + NL - 1) % NL] : rs;  // a(l = i)
+              tok[jj] = (rp * e.y[jj]) * nx;
+              if (jj > 0) qal += S.c[jj] * rp;
             }
-            qb *= e.bl * KL;
-            p0 = S.cx * e.bl * r.tx;
+            qal *= e.bl;
+            qsh = ((S.c[0] * rs) * e.bl) * KS;
+            tok[0] *= KS;
+            p0 = S.cx * e.bl * r0;
           }
-          // the state outside the slot range (uniform): into lane 0's blank part
-          const int k0 = S.kx + r.kt - lp_int;
-          kflag |= (p0 > 0.f && k0 > KK_MAX);
-          const float q0 = p0 * ldexp_f(cf30, imin(k0, KK_MAX));
-          qb += (lane == 0) ? q0 : 0.f;
-#ifdef CTC_F6_DEBUG2
-          if (DIR == 0 && j == 0 && d < 4 && NL == 2) {  // main A, first phase-2 block, frames d = 0..3: what goes into the S row
-            int *dbg = flag_ws + p.B + (long)b * 2048;
-            dbg[(d * 8 + 0) * 64 + lane] = __float_as_int(qb); dbg[(d * 8 + 1) * 64 + lane] = __float_as_int(qt[0]);
-            dbg[(d * 8 + 2) * 64 + lane] = __float_as_int(qt[NL - 1]); dbg[(d * 8 + 3) * 64 + lane] = S.k;
-            dbg[(d * 8 + 4) * 64 + lane] = kR; dbg[(d * 8 + 5) * 64 + lane] = __float_as_int(r.a[0]);
-            dbg[(d * 8 + 6) * 64 + lane] = __float_as_int(r.a[NL - 1]); dbg[(d * 8 + 7) * 64 + lane] = __float_as_int(S.c[0]);
-          }
-#endif
-          // S row in place of the R row: per lane [qb, qt[0..NL-1]] in a region of 2 NL floats
+          const float q0 = p0 * K0;  // the boundary state (uniform)
           float *srow = RR[d] + 2 * lane * NL;
-          if constexpr (NL == 1) *reinterpret_cast<float2 *>(srow) = make_float2(qb, qt[0]);
-          else if constexpr (NL == 2) *reinterpret_cast<float4 *>(srow) = make_float4(qb, qt[0], qt[1], 0.f);
+          if constexpr (NL == 1) *reinterpret_cast<float2 *>(srow) = make_float2(tok[0], qsh);
+          else if constexpr (NL == 2) *reinterpret_cast<float4 *>(srow) = make_float4(qal, tok[0], tok[1], qsh);
           else {
-            *reinterpret_cast<float4 *>(srow) = make_float4(qb, qt[0], qt[1], qt[2]);
-            srow[4] = qt[3];
+            *reinterpret_cast<float4 *>(srow) = make_float4(qal, tok[0], tok[1], tok[2]);
+            *reinterpret_cast<float2 *>(srow + 4) = make_float2(tok[3], qsh);
           }
+          KLr[d][lane] = KL;
+          float *tq = (lane == 0) ? RR[d] + 2 * LD::UP : dump + lane;  // lanes > 0 write a sink
+          *tq = q0;
           if constexpr (!(KIND == 0 && DIR == 0)) S.step(e);
           if (ren) { S.template renorm<LV>(); setK(); }
         };
@@ -949,7 +963,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
       }
       F6_BARRIER();
     }
-    (void)kflag;
+    if (__builtin_amdgcn_ballot_w64(kflag != 0) != 0 && lane == 0) atomicOr(&lds.flag, 32);  // D5
   }
   __syncthreads();  // every role's phase-2 flags are in
   if (DIR == 0 && lane == 0) flag_ws[b] = lds.flag;
@@ -1021,12 +1035,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
       restore<KIND, NL, RDIR>(S, ck);
       KG[0][lane] = S.k;
       int s = 0;  // steps since the checkpoint
-      auto put = [&](int d) __attribute__((always_inline)) {
-        float cs[NL], tx;
-        int kt;
-        S.other_order(cs, tx, kt);
-        write_R<KIND, NL, LD>(RR[d], dump, lane, cs, S.o, tx, kt);
-      };
+      auto put = [&](int d) __attribute__((always_inline)) { write_R<KIND, NL, LD>(RR[d], dump, lane, S.c, S.o, S.cx, S.kx); };
       // one step, its row, then (every RN steps, if more rows follow) a renormalisation that opens the next exponent group
       Emis<NL> eb[BLK];  // full blocks: the emission rows go to registers before the chain starts
       if (nv == BLK) static_for<0, BLK>([&](auto D) { read_E<NL, LD>(E[decltype(D)::value], lane, eb[decltype(D)::value]); });
@@ -1225,33 +1234,49 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         const int g = geo.absblock(2, DIR, gj);
         const int nv = geo.nvof(g);
         const float(*SR)[LD::RS] = lds.R[DIR][gj % 3];
+        const float(*KLr)[64] = lds.kl[DIR][gj % 3];
+        // S row entry -> blank posterior of the lane and token posteriors of its slots, all in units of 2^-30 (see run_main)
         auto read_S = [&](int d, float &qb, float (&qt)[NL]) __attribute__((always_inline)) {
           const float *srow = SR[d] + 2 * lane * NL;
-          if constexpr (NL == 1) { const float2 t = *reinterpret_cast<const float2 *>(srow); qb = t.x; qt[0] = t.y; }
-          else if constexpr (NL == 2) { const float4 t = *reinterpret_cast<const float4 *>(srow); qb = t.x; qt[0] = t.y; qt[1] = t.z; }
-          else { const float4 t = *reinterpret_cast<const float4 *>(srow); qb = t.x; qt[0] = t.y; qt[1] = t.z; qt[2] = t.w; qt[3] = srow[4]; }
+          const float kl = KLr[d][lane];
+          const float q0 = SR[d][2 * LD::UP];  // same address in every lane: LDS broadcast
+          constexpr int JS = (KIND == 1) ? (DIR == 0 ? NL - 1 : 0) : -1;  // simplified: the slot whose token part is already scaled
+          float qal = 0.f, qsh;
+          if constexpr (NL == 1) { const float2 t = *reinterpret_cast<const float2 *>(srow); qt[0] = t.x; qsh = t.y; }
+          else if constexpr (NL == 2) { const float4 t = *reinterpret_cast<const float4 *>(srow); qal = t.x; qt[0] = t.y; qt[1] = t.z; qsh = t.w; }
+          else {
+            const float4 t = *reinterpret_cast<const float4 *>(srow);
+            const float2 u = *reinterpret_cast<const float2 *>(srow + 4);
+            qal = t.x; qt[0] = t.y; qt[1] = t.z; qt[2] = t.w; qt[3] = u.x; qsh = u.y;
+          }
+#pragma unroll
+          for (int jj = 0; jj < NL; ++jj) if (jj != JS) qt[jj] *= kl;
+          qb = qal * kl + qsh + ((lane == 0) ? q0 : 0.f);
         };
         if (__builtin_expect(nv == BLK, 1)) {
-          float qb[2 * FPH], qt[FPH][NL];  // qb[FPH + q]: total posterior mass of the frame (D6)
+          // qb[FPH]: total posterior mass of this helper's first frame of the block (D6).  Mass lost by a chain is missing
+          // from every frame between the place of the loss and the end of that chain's range, so one frame per helper
+          // and block (4 spread over the 12) sees it.
+          float qb[FPH + 1], qt[FPH][NL];
           static_for<0, FPH>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             read_S(h + NH * q, qb[q], qt[q]);
-            qb[FPH + q] = qb[q];
-#pragma unroll
-            for (int jj = 0; jj < NL; ++jj) qb[FPH + q] += qt[q][jj];
           });
+          qb[FPH] = qb[0];
+#pragma unroll
+          for (int jj = 0; jj < NL; ++jj) qb[FPH] += qt[0][jj];
 #ifdef CTC_F6_DEBUG2
           if (DIR == 0 && gj == 0 && h == 1 && NL == 2) {  // what helper 1 of side A reads for position d = 1 of the first block
             int *dbg = flag_ws_dbg + p.B + (long)b * 2048 + 1024;
             dbg[lane] = __float_as_int(qb[0]); dbg[64 + lane] = __float_as_int(qt[0][0]); dbg[128 + lane] = __float_as_int(qt[0][NL - 1]);
           }
 #endif
-          dpp_sum_n<2 * FPH>(qb);  // blank posteriors and total masses of the FPH frames, one batched wave reduction
+          dpp_sum_n<FPH + 1>(qb);  // blank posteriors of the FPH frames and one total mass, one batched wave reduction
+          massbad |= !(fabsf(readlane_f(qb[FPH], 63) - 1073741824.0f) < 1073741824.0f * 1e-4f);
           static_for<0, FPH>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             const int d = h + NH * q;
             const float qbs = readlane_f(qb[q], 63);
-            massbad |= !(fabsf(readlane_f(qb[FPH + q], 63) - 1073741824.0f) < 1073741824.0f * 1e-4f);
             if constexpr (RELOAD) {
               float4 ev[VPL];
               S.expo(XG[q], readlane_f(sgl.x, d), ev);

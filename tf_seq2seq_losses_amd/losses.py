@@ -82,10 +82,12 @@ class _HessianContraction(torch.autograd.Function):
         raise NotImplementedError("Third order derivative over the ctc loss function is not implemented.")
 
 
-# Below this many logits the forward pass also produces the (unit) gradient and backward rescales it -- one launch instead
-# of two, which is what matters when launches dominate; above it the forward pass computes the loss only and backward runs
-# the kernel again with d_loss applied inside it -- no [B,T,V] tensor kept alive in between and no extra pass over it.
-_EAGER_GRADIENT_MAX_ELEMENTS = 1 << 22
+# When the logits require a gradient the forward pass produces loss AND unit gradient in ONE kernel launch (the gradient
+# costs the kernel nothing extra to speak of: it is the second half of the same launch) and backward only rescales it.
+# The [B,T,V] gradient is kept alive between forward and backward, like the activations it belongs to; a caller that
+# cannot afford that (it is 0.1 % of the HBM at the north-star size) sets EAGER_GRADIENT_MAX_ELEMENTS lower: above the
+# limit forward computes the loss only and backward runs the kernel again with d_loss applied inside it.
+EAGER_GRADIENT_MAX_ELEMENTS = 1 << 40
 
 
 class _CtcGradient(torch.autograd.Function):
@@ -119,7 +121,7 @@ class _CtcLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, kind, wrt, prep):
-        eager = x.requires_grad and x.numel() <= _EAGER_GRADIENT_MAX_ELEMENTS
+        eager = x.requires_grad and x.numel() <= EAGER_GRADIENT_MAX_ELEMENTS
         loss, grad = ops.loss_grad(kind, wrt, prep, want_grad=eager)
         ctx.kind, ctx.wrt, ctx.prep = kind, wrt, prep
         if eager:

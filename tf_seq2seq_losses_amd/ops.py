@@ -9,7 +9,7 @@ import torch
 from . import _lib
 
 KINDS = {"classic": _lib.CLASSIC, "simplified": _lib.SIMPLIFIED}
-FUSED_MAX_U = 128  # label positions the fastest instantiation of the fused kernel holds (two per lane; 256 with four)
+FUSED_MAX_U = 256  # label positions the fused kernels hold (four per lane); wider label tensors may still have short labels
 
 
 def _require_gpu(t: torch.Tensor) -> None:
@@ -49,8 +49,9 @@ class Prepared:
         self.stride = int(self.labels.shape[1])
         # static bound on the label length: identical results to the reference's dynamic max(label_length)
         # (base_loss.py:482-486) without a device->host sync.  Only when the label tensor is wider than the fused
-        # kernels' 128 positions (e.g. padded to the frame count, tests/common.py:89-94) is the maximum fetched -- one
-        # small sync that lets such batches take the fused path when their labels are in fact short.
+        # kernels' 256 positions (e.g. padded to a long frame count, tests/common.py:89-94) is the maximum fetched -- one
+        # small sync (not capturable into a graph) that lets such batches take the fused path when their labels are in
+        # fact short; pass U explicitly to avoid it.
         if U is None:
             U = self.stride
             if U > FUSED_MAX_U and self.label_length.numel() > 0:
@@ -74,9 +75,24 @@ class Prepared:
                 _ptr(self.logit_length), self.blank, self.B, self.T, self.V, self.U)
 
 
+_WS_BYTES = {}   # (what, kind, B, T, V, U) -> bytes: no ctypes round trip per call
+_WS_CACHE = {}   # (device, stream) -> the loss+gradient workspace last used there (reused while it is large enough)
+
+
 def _workspace(what: int, kind: int, p: Prepared) -> torch.Tensor:
-    n = _lib.workspace_bytes(what, kind, p.B, p.T, p.V, p.U)
-    return torch.empty(max(n, 1), dtype=torch.uint8, device=p.device)
+    key = (what, kind, p.B, p.T, p.V, p.U)
+    n = _WS_BYTES.get(key)
+    if n is None:
+        n = _WS_BYTES[key] = _lib.workspace_bytes(what, kind, p.B, p.T, p.V, p.U)
+    if what != _lib.WS_LOSS_GRAD:
+        return torch.empty(max(n, 1), dtype=torch.uint8, device=p.device)
+    # The loss+gradient workspace is scratch that lives only for the duration of one call.  Calls on one stream are
+    # ordered, so they can share one buffer; another stream gets its own.
+    ck = (p.device, _stream(p.device))
+    ws = _WS_CACHE.get(ck)
+    if ws is None or ws.numel() < n:
+        ws = _WS_CACHE[ck] = torch.empty(max(n, 1), dtype=torch.uint8, device=p.device)
+    return ws
 
 
 def _stream(dev) -> int:
