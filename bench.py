@@ -104,6 +104,109 @@ def cpu_baseline(kind, host, budget_s=15.0):
     return out
 
 
+def _events_ms(fn, steps, warmup):
+    """Mean device time of fn() over `steps` calls (HIP events on torch's current stream = the launch stream) and the wall
+    time per call of the same loop."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    return sum(a.elapsed_time(b) for a, b in ev) / steps, wall * 1e3
+
+
+def _lossgrad_callable(lib, _lib, ops, kind, dev, B, T, U, V):
+    prep = ops.Prepared(dev["labels"], dev["logits"], dev["label_length"], dev["logit_length"], 0, U=U)
+    ws = torch.empty(_lib.workspace_bytes(_lib.WS_LOSS_GRAD, kind, B, T, V, U), dtype=torch.uint8, device=prep.device)
+    loss = torch.empty(B, dtype=torch.float32, device=prep.device)
+    grad = torch.empty((B, T, V), dtype=torch.float32, device=prep.device)
+    args_c = prep.common(kind, _lib.WRT_LOGITS) + (loss.data_ptr(), grad.data_ptr(), None, ws.data_ptr(), ws.numel())
+
+    def step():
+        rc = lib.ctc_amd_loss_grad(*args_c, torch.cuda.current_stream().cuda_stream)
+        if rc:
+            _lib.check(rc, "ctc_amd_loss_grad")
+        return loss
+    step.keep = (prep, ws, loss, grad)
+    return step
+
+
+def _roof(alg_bytes, kernel_ms, **extra):
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    return dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                algorithmic_bytes_per_launch=alg_bytes, kernel_ms_per_launch=kernel_ms, **extra)
+
+
+def secondary(device, rank):
+    """The other configurations of BASELINE.json and the callers around the path, timed in the same process after the
+    headline (each entry: device time per call by HIP events, its HBM-roofline fraction, utterances/s from the wall time)."""
+    from tf_seq2seq_losses_amd import _lib, ops
+    import tf_seq2seq_losses_amd as ctc
+    lib = _lib.load()
+    out = {}
+    B, T, U, V = 256, 1000, 128, 256
+    alg = B * 2 * T * V * 4
+
+    def lossgrad(name, kind_name, ragged, seed):
+        host, dev = make_inputs(B, T, U, V, seed=seed, ragged=ragged, device=device)
+        step = _lossgrad_callable(lib, _lib, ops, ops.KINDS[kind_name], dev, B, T, U, V)
+        kms, wms = _events_ms(step, 50, 10)
+        frames = int(host["logit_length"].sum())
+        out[name] = dict(workload=f"{kind_name}_ctc_loss loss+grad B={B} T={T} U={U} V={V} fp32 {'ragged' if ragged else 'full-length'}",
+                         value=B / (wms * 1e-3), unit="utterances/s", ms_per_step=wms,
+                         pipeline=_lib.pipeline_name(ops.KINDS[kind_name], 0, B, T, V, U, True),
+                         roofline=_roof(alg if not ragged else frames * 2 * V * 4, kms, traffic=None))
+
+    lossgrad("config3_simplified", "simplified", False, rank)
+    lossgrad("classic_ragged", "classic", True, 1)
+
+    # the drop-in Python call: classic_ctc_loss + autograd.grad(mean(loss)) (tests/benchmark.py:195-201 of the reference)
+    host, dev = make_inputs(B, T, U, V, seed=rank, ragged=False, device=device)
+    x = dev["logits"].clone().requires_grad_(True)
+
+    def dropin():
+        loss = ctc.classic_ctc_loss(dev["labels"], x, dev["label_length"], dev["logit_length"], 0)
+        return torch.autograd.grad(loss.mean(), x)[0]
+    kms, wms = _events_ms(dropin, 50, 10)
+    out["dropin_autograd"] = dict(workload=f"classic_ctc_loss(...) + autograd.grad(loss.mean(), logits) through the Python mirror, B={B} T={T} U={U} V={V}",
+                                  value=B / (wms * 1e-3), unit="utterances/s", ms_per_step=wms,
+                                  roofline=_roof(alg, kms, traffic=None, note="device time of forward (loss) + backward (gradient) incl. the mean and its backward"))
+
+    # Hessian-vector product (second-order backward), north-star shape
+    prep = ops.Prepared(dev["labels"], dev["logits"], dev["label_length"], dev["logit_length"], 0, U=U)
+    vec = torch.randn((B, T, V), device=device, generator=torch.Generator(device=device).manual_seed(0))
+    kms, wms = _events_ms(lambda: ops.hvp(ops.KINDS["classic"], _lib.WRT_LOGITS, prep, vec), 10, 3)
+    out["hvp"] = dict(workload=f"ctc_amd_hvp (Hessian-vector product, no [B,T,V,T,V] tensor) B={B} T={T} U={U} V={V}",
+                      value=B / (wms * 1e-3), unit="utterances/s", ms_per_step=wms,
+                      roofline=_roof(B * 3 * T * V * 4, kms, traffic=None, note="algorithmic bytes: logits + vector read, product written"))
+    del vec, x
+
+    # configs[4]: dense Hessian B=32 T=200 U=32 V=64
+    Bh, Th, Uh, Vh = 32, 200, 32, 64
+    hostb, devb = make_inputs(Bh, Th, Uh, Vh, seed=rank, ragged=False, device=device)
+    prep = ops.Prepared(devb["labels"], devb["logits"], devb["label_length"], devb["logit_length"], 0, U=Uh)
+    kindc = ops.KINDS["classic"]
+    ws = torch.empty(_lib.workspace_bytes(_lib.WS_HESSIAN, kindc, Bh, Th, Vh, Uh), dtype=torch.uint8, device=device)
+    loss = torch.empty(Bh, dtype=torch.float32, device=device)
+    hess = torch.empty((Bh, Th, Vh, Th, Vh), dtype=torch.float32, device=device)
+
+    def hstep():
+        rc = lib.ctc_amd_hessian(*prep.common(kindc, _lib.WRT_LOGITS), loss.data_ptr(), None, hess.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "ctc_amd_hessian")
+    kms, wms = _events_ms(hstep, 5, 2)
+    out["config5_hessian"] = dict(workload=f"classic_ctc_loss dense Hessian B={Bh} T={Th} U={Uh} V={Vh} fp32 (one ctc_amd_hessian call)",
+                                  value=Bh / (wms * 1e-3), unit="utterances/s", ms_per_step=wms,
+                                  roofline=_roof(Bh * ((Th * Vh) ** 2 * 4 + Th * Vh * 4), kms, traffic=None))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +220,7 @@ def main():
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--hessian", action="store_true", help="time the dense Hessian at B=32 T=200 U=32 V=64 (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (simplified, ragged, drop-in autograd, HVP, Hessian)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="element type of logits and gradient (producer format)")
     ap.add_argument("--time-major", action="store_true", help="logits stored [T,B,V] (producer format), passed as a strided view")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -255,20 +359,24 @@ def main():
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         if args.hessian:
             kernel_name = "emit_kernel + scan_kernel + grad_kernel (x2) + hess_slab_kernel (one ctc_amd_hessian call; hess_slab_kernel is >99 % of it)"
-            traffic = None
+            traffic = traffic_src = None
         else:
             pipeline = _lib.pipeline_name(kind, _lib.WRT_LOGITS, B, T, V, U, True)
             kernel_name = {"fused6": "fused6_kernel (one launch: linear-domain chains + recompute chains + helpers) + the fused5_kernel launch for flagged utterances (none here)",
                            "fused5": "fused5_kernel (one launch: chains + recompute chains + helpers)",
                            "fused2": "fused_kernel",
                            "v1": "emit_kernel + scan_kernel + grad_kernel"}[pipeline] + " = one ctc_amd_loss_grad call"
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r01_fused5_pmc_traffic.json")
-            if pipeline == "fused5x" and args.kind == "classic" and (B, T, U, V) == (256, 1000, 128, 256) and not args.ragged \
-                    and args.dtype == "f32" and not args.time_major \
-                    and os.path.exists(tfile):
-                # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file's note)
-                traffic = json.load(open(tfile)).get("_total_bytes_per_call")
+            # HBM bytes per launch from committed rocprofv3 PMC passes of this configuration (FETCH_SIZE x2 + WRITE_SIZE, see the
+            # file's note).  Only quoted when the profiled kernel is the one this run launches (name with template arguments).
+            traffic, traffic_src = None, None
+            tfile = os.path.join(ROOT, "profiles", "r02_fused6_pmc_traffic.json")
+            north_star = args.kind == "classic" and (B, T, U, V) == (256, 1000, 128, 256) and not args.ragged and args.dtype == "f32" and not args.time_major
+            if north_star and os.path.exists(tfile):
+                prof = json.load(open(tfile))
+                running = f"ctc::{pipeline}::{pipeline}_kernel<0, 2, 4, 12, 1, 0>"
+                if prof.get("_kernel") == running:
+                    traffic = prof.get("_total_bytes_per_call")
+                    traffic_src = f"{os.path.basename(tfile)} (kernel {prof.get('_kernel')}, commit {prof.get('_commit')})"
         out = {
             "metric": "utterances/sec (loss+grad) at B=256 T=1000 U=128 V=256; HBM roofline %" if not args.hessian
             else "utterances/sec (dense Hessian) at B=32 T=200 U=32 V=64",
@@ -279,7 +387,7 @@ def main():
                                    + (" ragged" if args.ragged else " full-length") + (" time-major [T,B,V]" if args.time_major else ""),
                        "global_batch": B * world, "parallelism": f"batch-sharded x{world}, all-reduce of sum(loss)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src if not args.hessian else None,
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_ms_per_launch": kernel_ms, "device_ms_per_step_incl_reduction": dev_ms_per_step},
         }
@@ -287,6 +395,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.kind, host)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_secondary and not args.hessian and (B, T, U, V) == (256, 1000, 128, 256):
+            out["secondary"] = secondary(device, rank)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

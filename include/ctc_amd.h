@@ -51,6 +51,17 @@ extern "C" {
 #define CTC_AMD_EINVAL (-1)     /* bad argument (null pointer, negative size, unsupported shape)      */
 #define CTC_AMD_EWORKSPACE (-2) /* workspace too small                                                */
 #define CTC_AMD_EHIP (-3)       /* HIP runtime error (launch failure)                                 */
+#define CTC_AMD_ELABEL (-4)     /* ctc_amd_check_labels: a label outside [0, V) or equal to the blank */
+
+/* Limits (CTC_AMD_EINVAL beyond them; the reference has none, its cost just grows):
+ *   U <= CTC_AMD_MAX_U          label positions (16 per lane of one wavefront)
+ *   V <= CTC_AMD_MAX_V          tokens for loss / gradient / alpha-beta (one 64 KB LDS token row per wavefront)
+ *   V <= CTC_AMD_MAX_V_HESSIAN  tokens for ctc_amd_hessian / ctc_amd_hvp (V + 4 floats of LDS per wavefront)
+ * Vector (16-byte / 8-byte) row accesses are used when V, the strides AND the base pointers are aligned; any other
+ * alignment runs element-wise paths with identical results. */
+#define CTC_AMD_MAX_U 1024
+#define CTC_AMD_MAX_V 16384
+#define CTC_AMD_MAX_V_HESSIAN 16380
 
 /* selector for ctc_amd_workspace_bytes */
 #define CTC_AMD_WS_LOSS_GRAD 0
@@ -79,6 +90,16 @@ const char *ctc_amd_pipeline_name(int kind, int wrt, int B, int T, int V, int U,
  * The library never reads the environment.  Returns CTC_AMD_EINVAL for an unknown key or value.
  */
 int ctc_amd_debug_override(const char *key /*host*/, const char *value /*host*/);
+
+/*
+ * Opt-in validation of the labels (the ONLY entry point that synchronises the stream and allocates -- a few bytes from the
+ * stream-ordered pool; keep it off the hot path).  Returns CTC_AMD_ELABEL if any label inside label_length (and inside
+ * U / label_stride) lies outside [0, V) or equals blank_index.  Without this check such a label is not an error in the
+ * compute entry points: it is an impossible emission, the sample comes out infeasible (loss +inf, zero gradient).
+ * Replaces: the InvalidArgumentError of tf.gather on TF-CPU for out-of-range labels (base_loss.py:328-344).
+ */
+int ctc_amd_check_labels(const int32_t *labels, int label_stride, const int32_t *label_length, int blank_index,
+                         int B, int V, int U, void *stream);
 
 /* Bytes of device workspace the call selected by `what` needs for these shapes. */
 int ctc_amd_workspace_bytes(int what, int kind, int B, int T, int V, int U, size_t *out_bytes /*host*/);
@@ -143,6 +164,27 @@ int ctc_amd_loss_grad_ex(int kind, int wrt,
                          float *loss, void *grad, int grad_dtype, int64_t grad_stride_b, int64_t grad_stride_t,
                          const float *d_loss,
                          void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Second half of a forward -> backward pair: the gradient for a loss that ctc_amd_loss_grad / ctc_amd_loss_grad_ex has just
+ * computed with grad == NULL, weighted by d_loss (which a training loop only knows once the backward pass runs).
+ * Replaces: forward_fn.backprop (base_loss.py:150-153) when the forward pass has already run.
+ * The loss-only call stops where the alpha and beta chains meet and leaves its checkpoints, the softmax statistics and
+ * log P in the workspace; this call runs the remaining half of the same kernel from there (together: one loss+gradient
+ * call's work, split over two launches).  Contract: same arguments as that loss-only call, same workspace, nothing else
+ * written to the workspace in between.  `loss` is rewritten with the same values for the utterances that the log-domain
+ * kernel redoes (normally none).  Shapes that do not run the linear-domain fused kernel ("fused6") compute loss and
+ * gradient anew, so the call is always valid after ANY loss-only call with the same arguments.
+ * Workspace: CTC_AMD_WS_LOSS_GRAD.
+ */
+int ctc_amd_grad_resume(int kind, int wrt,
+                        const void *logits, int logits_dtype, int64_t logits_stride_b, int64_t logits_stride_t,
+                        const int32_t *labels, int label_stride,
+                        const int32_t *label_length, const int32_t *logit_length, int blank_index,
+                        int B, int T, int V, int U,
+                        float *loss, void *grad, int grad_dtype, int64_t grad_stride_b, int64_t grad_stride_t,
+                        const float *d_loss,
+                        void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Hessian-vector product  out[b,t,k] = sum_{t2,k2} H[b,t,k,t2,k2] * vec[b,t2,k2]  without materialising H

@@ -21,5 +21,7 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(100):
     step()
+t_submit = time.perf_counter() - t0
 torch.cuda.synchronize()
+print(f"host submit time per step {t_submit / 100 * 1e3:.3f} ms")
 print(f"classic_ctc_loss + autograd.grad(loss.sum()) at B={B} T={T} U={U} V={V}: {(time.perf_counter() - t0) / 100 * 1e3:.3f} ms")

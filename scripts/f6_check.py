@@ -47,13 +47,13 @@ def flags_of(ws, kind, B, T, V, U):
         fl = ws[o:o + 4 * B].view(torch.int32).cpu().numpy()
         dbg = ws[o + 4 * B:o + 4 * B + B * 2048 * 4].view(torch.int32).cpu().numpy().reshape(B, 2048)[:, :512].reshape(B, 2, 4, 64)
         shown = 0
-        for b in np.nonzero(fl)[0]:
+        for b in range(B):
             for d in range(2):
                 lanes = np.nonzero(dbg[b, d, 0])[0]
                 if len(lanes) and shown < 12:
                     shown += 1
-                    print(f"   b={b} dir={d} flag={hex(fl[b])} dead lanes {lanes.tolist()} renorm# {dbg[b, d, 0, lanes].tolist()} k_before {dbg[b, d, 1, lanes].tolist()} "
-                          f"last max {dbg[b, d, 2, lanes].view(np.float32).tolist()} k_end(all lanes) {dbg[b, d, 3].tolist()}")
+                    print(f"   b={b} dir={d} flag={hex(fl[b])} D3 lanes {lanes.tolist()} renorm# {dbg[b, d, 0, lanes].tolist()} d {dbg[b, d, 1, lanes].tolist()} "
+                          f"fe {dbg[b, d, 2, lanes].tolist()} k_end(lanes 0..63) {dbg[b, d, 3].tolist()}")
     return ws[o:o + 4 * B].view(torch.int32).cpu().numpy()
 
 
@@ -120,7 +120,7 @@ if __name__ == "__main__":
         run("simplified", 2, 48, 100, 256, ragged=False)
         run("simplified", 2, 150, 65, 256, ragged=False)
     if which == "seeds":
-        for sd in range(8):
+        for sd in range(int(os.environ.get("F6_NSEEDS", "8"))):
             run("classic", 256, 1000, 128, 256, seed=sd, ncheck=2, reps=10)
     if which == "b128":
         run("classic", 128, 1000, 128, 256, seed=2, ncheck=2, reps=50)

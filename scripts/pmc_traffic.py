@@ -18,12 +18,13 @@ def mean_per_dispatch(path, counter, sub):
 
 
 fetch_csv, write_csv, sub, out = sys.argv[1:5]
+commit = sys.argv[5] if len(sys.argv) > 5 else None
 name, fkb, n = mean_per_dispatch(fetch_csv, "FETCH_SIZE", sub)
 _, wkb, _ = mean_per_dispatch(write_csv, "WRITE_SIZE", sub)
 res = {name: {"fetch_kb_raw": fkb, "write_kb": wkb, "fetch_bytes_corrected": fkb * 1024 * 2, "write_bytes": wkb * 1024, "launches": n},
        "_total_bytes_per_call": fkb * 1024 * 2 + wkb * 1024,
-       "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python3 bench.py --steps 4 --warmup 1 "
-                "--no-cpu-baseline`; KB per dispatch averaged; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 "
+       "_kernel": name, "_commit": commit,
+       "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python3 scripts/lossgrad_once.py`; KB per dispatch averaged; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 "
                 "of wide coalesced reads); WRITE_SIZE exact for 16-B/lane stores."}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-qprof}
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline ${@:2} > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary ${@:2} > $OUT/stats.log 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/stats/*/*_kernel_stats.csv")[0]

@@ -74,3 +74,51 @@ def test_cpu_tensors_fail_loudly():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ctc.classic_ctc_loss(torch.zeros((1, 2), dtype=torch.int32), torch.zeros((1, 3, 4)),
                              torch.zeros(1, dtype=torch.int32), torch.zeros(1, dtype=torch.int32))
+
+
+def test_limits_are_reported_not_crashed_into(lib):
+    """include/ctc_amd.h "Limits": U <= 1024, V <= 16384 (loss / gradient), V <= 16380 (Hessian, HVP): exactly at the limit
+    the argument checks pass (here they then stop at the missing workspace), one past it they return CTC_AMD_EINVAL."""
+    from tf_seq2seq_losses_amd import _lib
+    text = open(os.path.join(ROOT, "include", "ctc_amd.h")).read()
+    lim = {k: int(v) for k, v in re.findall(r"#define (CTC_AMD_MAX_[A-Z_]+) (\d+)", text)}
+    assert lim == {"CTC_AMD_MAX_U": 1024, "CTC_AMD_MAX_V": 16384, "CTC_AMD_MAX_V_HESSIAN": 16380}
+    one = ctypes.c_void_p(16)  # a non-null, never dereferenced pointer: validation happens before any launch
+
+    def loss_grad(U, V, grad=one):
+        return lib.ctc_amd_loss_grad(0, 0, one, one, U, one, one, 0, 1, 1, V, U, one, grad, None, None, 0, None)
+
+    def hessian(V):
+        return lib.ctc_amd_hessian(0, 0, one, one, 1, one, one, 0, 1, 1, V, 1, one, None, one, None, 0, None)
+
+    def hvp(V):
+        return lib.ctc_amd_hvp(0, 0, one, one, 1, one, one, 0, 1, 1, V, 1, one, one, None, one, None, 0, None)
+
+    assert loss_grad(1024, 8) == _lib.EWORKSPACE and loss_grad(1025, 8) == _lib.EINVAL
+    assert b"U=1025" in lib.ctc_amd_last_error()
+    assert loss_grad(4, 16384) == _lib.EWORKSPACE and loss_grad(4, 16385) == _lib.EINVAL
+    assert loss_grad(4, 20000, grad=None) == _lib.EWORKSPACE        # the loss alone has no vocabulary limit
+    assert hessian(16380) == _lib.EWORKSPACE and hessian(16381) == _lib.EINVAL
+    assert hvp(16380) == _lib.EWORKSPACE and hvp(16381) == _lib.EINVAL
+    with pytest.raises(ValueError):
+        _lib.workspace_bytes(_lib.WS_LOSS_GRAD, 0, 1, 1, 8, 1025)
+
+
+def test_debug_override_validation(lib):
+    from tf_seq2seq_losses_amd import _lib
+    for key, val in (("pipeline", "v1"), ("pipeline", "fused2"), ("pipeline", "fused5"), ("pipeline", ""), ("hessian", "slab"), ("hessian", "")):
+        _lib.debug_override(key, val)
+    assert _lib.pipeline_name(0, 0, 256, 1000, 256, 128) == "fused6"
+    _lib.debug_override("pipeline", "fused5")
+    try:
+        assert _lib.pipeline_name(0, 0, 256, 1000, 256, 128) == "fused5"
+        assert _lib.pipeline_name(0, 0, 256, 1000, 2048, 128) == "v1"
+    finally:
+        _lib.debug_override("pipeline", "")
+    for key, val in (("pipeline", "fused"), ("pipeline", "f"), ("hessian", "x"), ("nope", "")):
+        with pytest.raises(ValueError):
+            _lib.debug_override(key, val)
+    # the library never reads the environment
+    for f in os.listdir(os.path.join(ROOT, "tf_seq2seq_losses_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(ROOT, "tf_seq2seq_losses_amd", "csrc", f)).read(), f

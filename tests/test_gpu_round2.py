@@ -1,0 +1,203 @@
+"""Round-2 additions to the boundary, each against the float64 C oracle:
+
+* ctc_amd_grad_resume: loss-only call + gradient call on the same workspace == one loss+gradient call (every pipeline);
+* the linear-domain kernel's fallback: inputs beyond its range (sharp logits, -inf, 1e10) are flagged and redone by the
+  log-domain kernel -- the answer must be the oracle's either way, and benign inputs must not be flagged;
+* ctc_amd_check_labels (CTC_AMD_ELABEL);
+* a label equal to the blank inside label_length: infeasible in every pipeline;
+* logits / gradient views whose base pointers are not 16-byte aligned, with sentinel regions around the output.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as C
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(_dev())
+
+
+def _case(B, T, U, V, seed, scale=1.0, ragged=True):
+    rng = np.random.default_rng(seed)
+    logits = (rng.standard_normal((B, T, V)) * scale).astype(np.float32)
+    labels = rng.integers(1, V, (B, U)).astype(np.int32)
+    if ragged:
+        tl = rng.integers(T // 2, T + 1, B).astype(np.int32)
+        ll = rng.integers(U // 2, U + 1, B).astype(np.int32)
+    else:
+        tl, ll = np.full(B, T, np.int32), np.full(B, U, np.int32)
+    return logits, labels, ll, tl
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+@pytest.mark.parametrize("pipeline", ["", "fused5", "fused2", "v1"])
+@pytest.mark.parametrize("B,T,U,V", [(5, 97, 20, 256), (3, 150, 100, 256), (4, 60, 9, 29)])
+def test_loss_then_resume_equals_one_call(kind, pipeline, B, T, U, V):
+    from tf_seq2seq_losses_amd import ops, _lib
+    logits, labels, ll, tl = _case(B, T, U, V, seed=B + T)
+    ll[0] = min(U, tl[0] + 5) if kind == "simplified" else ll[0]  # maybe infeasible: must come out +inf / zero gradient both ways
+    p = ops.Prepared(_t(labels), _t(logits), _t(ll), _t(tl), 0, U=U)
+    k = ops.KINDS[kind]
+    w = torch.tensor(np.linspace(0.5, 2.0, B).astype(np.float32), device=_dev())
+    _lib.debug_override("pipeline", pipeline)
+    try:
+        loss1, grad1 = ops.loss_grad(k, _lib.WRT_LOGITS, p, True, d_loss=w)
+        loss2, ws = ops.loss_forward(k, _lib.WRT_LOGITS, p)
+        grad2 = ops.grad_resume(k, _lib.WRT_LOGITS, p, loss2, ws, d_loss=w)
+        grad3 = ops.grad_resume(k, _lib.WRT_LOGITS, p, loss2, ws, d_loss=w)   # the workspace survives a resume: backward twice
+    finally:
+        _lib.debug_override("pipeline", "")
+    assert torch.equal(loss1, loss2)
+    assert torch.equal(grad1, grad2) and torch.equal(grad2, grad3)
+    rl, rg = C.loss_grad(kind, labels, logits, ll, tl, 0)
+    fin = np.isfinite(rl)
+    assert np.array_equal(np.isfinite(loss1.cpu().numpy()), fin)
+    assert np.abs(grad2.cpu().numpy() - rg * w.cpu().numpy()[:, None, None]).max() < TOL
+
+
+def _flags(ws, kind, B, T, V, U):
+    """per-utterance flags the linear-domain kernel left in the workspace (Layout::off_flags of csrc/ctc_common.h)"""
+    al = lambda x: (x + 255) & ~255
+    nl = 1
+    while nl * 64 < U:
+        nl *= 2
+    UP = nl * 64; ERS = UP + 4; SRS = (2 * UP if kind == 0 else UP) + 8
+    o = al(B * T * ERS * 4); o = al(o + B * (T + 1) * SRS * 4); o = al(o + B * (T + 1) * SRS * 4)
+    o = al(o + B * 8); o = al(o + B * 2 * 1024); o = al(o + B * 4)
+    o = al(o + B * 2 * ((T + 5) // 6 + 3) * 64 * 4)
+    return ws[o:o + 4 * B].view(torch.int32).cpu().numpy()
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_linear_kernel_flags_what_it_cannot_hold_and_nothing_else(kind):
+    """Benign logits (N(0,1), the benchmark distribution): no utterance is flagged and the gradient is the float64 one to
+    1e-5 at T = 1000 (the log-domain kernel: 2.6e-4).  Sharp logits (N(0, 3^2) at T = 1000), -inf columns and 1e10:
+    flagged, redone in the log domain, still the oracle's answer."""
+    from tf_seq2seq_losses_amd import ops, _lib
+    k = ops.KINDS[kind]
+    B, T, U, V = 16, 1000, 128, 256
+    logits, labels, ll, tl = _case(B, T, U, V, seed=0, ragged=False)
+    p = ops.Prepared(_t(labels), _t(logits), _t(ll), _t(tl), 0, U=U)
+    ws = torch.zeros(_lib.workspace_bytes(_lib.WS_LOSS_GRAD, k, B, T, V, U), dtype=torch.uint8, device=_dev())
+    loss, grad = ops.loss_grad(k, _lib.WRT_LOGITS, p, True, workspace=ws)
+    assert not _flags(ws, k, B, T, V, U).any()
+    rl, rg = C.loss_grad(kind, labels[:4], logits[:4], ll[:4], tl[:4], 0)
+    assert np.abs(grad[:4].cpu().numpy() - rg).max() < 1e-5
+    assert (np.abs(loss[:4].cpu().numpy() - rl) / rl).max() < 1e-6
+    # beyond the range of float32 mantissas with per-lane exponents
+    hard = logits[:6].copy() * 3.0
+    hard[4, :, 200:] = -np.inf
+    hard[5, 10, :] = 0.0
+    hard[5, 10, 7] = 1e10
+    p = ops.Prepared(_t(labels[:6]), _t(hard), _t(ll[:6]), _t(tl[:6]), 0, U=U)
+    labels6 = labels[:6].copy()
+    ws = torch.zeros(_lib.workspace_bytes(_lib.WS_LOSS_GRAD, k, 6, T, V, U), dtype=torch.uint8, device=_dev())
+    loss, grad = ops.loss_grad(k, _lib.WRT_LOGITS, p, True, workspace=ws)
+    assert _flags(ws, k, 6, T, V, U).all()
+    rl, rg = C.loss_grad(kind, labels6, hard, ll[:6], tl[:6], 0)
+    fin = np.isfinite(rl)
+    ln = loss.cpu().numpy()
+    assert np.array_equal(np.isfinite(ln), fin)
+    assert (np.abs(ln[fin] - rl[fin]) / np.abs(rl[fin])).max() < 1e-4
+    # (the log-domain kernel's own accuracy at T = 1000 with sharp logits: measured 6.6e-4 / 1.0e-3, classic / simplified;
+    # utterance 5 carries a 1e10 logit: its loss is ~1e10 and, as in the float32 reference, only the loss and the finiteness
+    # of the gradient are meaningful there -- tests/test_gpu_parity.py::test_extreme_logits)
+    gn = grad.cpu().numpy()
+    assert np.isfinite(gn).all()
+    cmp = fin.copy(); cmp[5] = False
+    assert np.abs(gn[cmp] - rg[cmp]).max() < 2e-3
+
+
+def test_check_labels():
+    from tf_seq2seq_losses_amd import _lib
+    lib = _lib.load()
+    B, U, V = 5, 7, 11
+    labels = np.random.default_rng(0).integers(1, V, (B, U)).astype(np.int32)
+    ll = np.array([7, 3, 0, 5, 7], np.int32)
+    lt, llt = _t(labels), _t(ll)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.ctc_amd_check_labels(lt.data_ptr(), U, llt.data_ptr(), 0, B, V, U, st) == 0
+    bad = labels.copy(); bad[1, 5] = V + 3; bad[2, 0] = -1         # outside label_length: not read, not an error
+    assert lib.ctc_amd_check_labels(_t(bad).data_ptr(), U, llt.data_ptr(), 0, B, V, U, st) == 0
+    bad = labels.copy(); bad[3, 4] = V                              # one past the vocabulary
+    assert lib.ctc_amd_check_labels(_t(bad).data_ptr(), U, llt.data_ptr(), 0, B, V, U, st) == _lib.ELABEL
+    assert b"1 label" in lib.ctc_amd_last_error()
+    bad = labels.copy(); bad[0, 0] = -2; bad[4, 6] = 0              # negative, and equal to the blank
+    assert lib.ctc_amd_check_labels(_t(bad).data_ptr(), U, llt.data_ptr(), 0, B, V, U, st) == _lib.ELABEL
+    assert b"2 label" in lib.ctc_amd_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(_lib.ELABEL, "ctc_amd_check_labels")
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+@pytest.mark.parametrize("V,U", [(256, 6), (40, 6)])
+def test_blank_inside_the_label_is_infeasible_in_every_pipeline(kind, V, U):
+    from tf_seq2seq_losses_amd import ops, _lib
+    B, T = 3, 30
+    logits, labels, ll, tl = _case(B, T, U, V, seed=3, ragged=False)
+    labels[1, 2] = 0  # the blank id inside label_length
+    p = ops.Prepared(_t(labels), _t(logits), _t(ll), _t(tl), 0, U=U)
+    rl, rg = C.loss_grad(kind, labels[[0, 2]], logits[[0, 2]], ll[[0, 2]], tl[[0, 2]], 0)
+    for pipeline in ("", "fused5", "fused2", "v1"):
+        _lib.debug_override("pipeline", pipeline)
+        try:
+            loss, grad = ops.loss_grad(ops.KINDS[kind], _lib.WRT_LOGITS, p, True)
+            loss_only, _ = ops.loss_grad(ops.KINDS[kind], _lib.WRT_LOGITS, p, False)
+        finally:
+            _lib.debug_override("pipeline", "")
+        ln, gn = loss.cpu().numpy(), grad.cpu().numpy()
+        assert ln[1] == np.inf and np.all(gn[1] == 0), pipeline
+        assert loss_only.cpu().numpy()[1] == np.inf, pipeline
+        assert np.abs(ln[[0, 2]] - rl).max() < TOL * np.abs(rl).max(), pipeline
+        assert np.abs(gn[[0, 2]] - rg).max() < TOL, pipeline
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("off", [1, 2, 3])
+def test_unaligned_base_pointers(kind, dtype, off):
+    """A [B,T,V] view that starts `off` elements into its storage (strides stay multiples of 4): the vector paths need
+    aligned bases as well, so these run element-wise; result identical to the aligned call, nothing written outside the view."""
+    from tf_seq2seq_losses_amd import ops, _lib
+    B, T, U, V = 3, 40, 8, 256
+    logits, labels, ll, tl = _case(B, T, U, V, seed=11)
+    x = _t(logits).to(dtype)
+    wide = torch.zeros((B, T, V + 8), dtype=dtype, device=_dev())
+    wide[:, :, off:off + V] = x
+    view = wide[:, :, off:off + V]
+    assert view.data_ptr() % 16 != 0 and view.stride(2) == 1
+    k = ops.KINDS[kind]
+    p0 = ops.Prepared(_t(labels), x, _t(ll), _t(tl), 0, U=U, keep_format=True)
+    p1 = ops.Prepared(_t(labels), view, _t(ll), _t(tl), 0, U=U, keep_format=True)
+    l0, g0 = ops.loss_grad(k, _lib.WRT_LOGITS, p0, True)
+    # gradient into a sentinel-filled buffer with the same offset view
+    lib = _lib.load()
+    gw = torch.full((B, T, V + 8), 777.0, dtype=dtype, device=_dev())
+    gv = gw[:, :, off:off + V]
+    loss = torch.empty(B, dtype=torch.float32, device=_dev())
+    ws = torch.empty(_lib.workspace_bytes(_lib.WS_LOSS_GRAD, k, B, T, V, U), dtype=torch.uint8, device=_dev())
+    dt = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
+    rc = lib.ctc_amd_loss_grad_ex(k, 0, view.data_ptr(), dt, view.stride(0), view.stride(1), p1.labels.data_ptr(), p1.stride,
+                                  p1.label_length.data_ptr(), p1.logit_length.data_ptr(), 0, B, T, V, U, loss.data_ptr(),
+                                  gv.data_ptr(), dt, gv.stride(0), gv.stride(1), None, ws.data_ptr(), ws.numel(),
+                                  torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.ctc_amd_last_error()
+    if dtype == torch.float32:   # same kernel, element-wise row accesses: identical arithmetic
+        assert torch.equal(loss, l0)
+    else:                        # bfloat16 rows that are not 8-byte aligned take the three-kernel pipeline
+        assert torch.allclose(loss, l0, rtol=2e-6, atol=0)
+    if dtype == torch.float32:
+        assert torch.allclose(gv, g0, rtol=0, atol=1e-6)
+    else:
+        assert ((gv.float() - g0.float()).abs() <= 2.0 ** -7 * g0.float().abs() + 1e-6).all()  # both rounded to bfloat16: one ulp apart at most
+    assert (gw[:, :, :off] == 777.0).all() and (gw[:, :, off + V:] == 777.0).all()

@@ -16,7 +16,7 @@ ABI_VERSION = 2
 CLASSIC, SIMPLIFIED = 0, 1
 WRT_LOGITS, WRT_LOGPROBS = 0, 1
 WS_LOSS_GRAD, WS_ALPHA_BETA, WS_HESSIAN, WS_HVP = 0, 1, 2, 3
-OK, EINVAL, EWORKSPACE, EHIP = 0, -1, -2, -3
+OK, EINVAL, EWORKSPACE, EHIP, ELABEL = 0, -1, -2, -3, -4
 F32, BF16 = 0, 1
 
 _c_int, _c_void_p, _c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
@@ -32,6 +32,7 @@ SIGNATURES = {
     "ctc_amd_last_error": (ctypes.c_char_p, []),
     "ctc_amd_pipeline_name": (ctypes.c_char_p, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "ctc_amd_debug_override": (_c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    "ctc_amd_check_labels": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "ctc_amd_workspace_bytes": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_size_t)]),
     "ctc_amd_loss_grad": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "ctc_amd_loss_grad_ex": (_c_int, [_c_int, _c_int, _c_void_p, _c_int, ctypes.c_int64, ctypes.c_int64,  # kind, wrt, logits, dtype, strides
@@ -39,6 +40,11 @@ SIGNATURES = {
                                       _c_int, _c_int, _c_int, _c_int,                                   # B, T, V, U
                                       _c_void_p, _c_void_p, _c_int, ctypes.c_int64, ctypes.c_int64,    # loss, grad, dtype, strides
                                       _c_void_p, _c_void_p, _c_size_t, _c_void_p]),                     # d_loss, ws, bytes, stream
+    "ctc_amd_grad_resume": (_c_int, [_c_int, _c_int, _c_void_p, _c_int, ctypes.c_int64, ctypes.c_int64,
+                                     _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int,
+                                     _c_int, _c_int, _c_int, _c_int,
+                                     _c_void_p, _c_void_p, _c_int, ctypes.c_int64, ctypes.c_int64,
+                                     _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "ctc_amd_alpha_beta": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "ctc_amd_hessian": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "ctc_amd_hvp": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
@@ -77,7 +83,7 @@ def check(rc: int, what: str) -> None:
     if rc == OK:
         return
     msg = load().ctc_amd_last_error().decode("utf-8", "replace")
-    if rc == EINVAL:
+    if rc in (EINVAL, ELABEL):
         raise ValueError(f"{what}: {msg}")
     raise CtcAmdError(f"{what} failed with code {rc}: {msg}")
 

@@ -30,7 +30,7 @@ inline bool fused5_eligible(const Problem &p, const Layout &L) {
   // producer formats: both tensors float32 or both bfloat16, strides keeping the 16-byte (8-byte) row accesses aligned
   // (bfloat16 needs 8-byte aligned rows: V and the strides multiples of 4; float32 takes any V <= 256 and any stride)
   return p.wrt == 0 && (p.V <= 512 || (p.V <= 1024 && L.NL <= 2)) && L.NL <= 4 && p.B > 0 && p.T > 0 && p.xdtype == p.gdtype &&
-         (p.xdtype == 0 || ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0);
+         (p.xdtype == 0 || (((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0 && (p.align_bits & 7) == 0));
 }
 inline hipError_t run_fused5(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, bool only_flagged, hipStream_t st) {
   switch (L.NL) {  // one translation unit of ctc_fused5.hip per (kind, label positions per lane)
@@ -55,7 +55,7 @@ inline hipError_t run_fused6(const Problem &p, const Layout &L, char *ws, float 
 }
 // shapes the two-wavefront fused kernel (ctc_fused.hip) is instantiated for: logits input, V in {256, 512, 1024}, U <= 256
 inline bool fused_eligible(const Problem &p, const Layout &L) {
-  return p.wrt == 0 && (p.V == 256 || p.V == 512 || p.V == 1024) && L.NL <= 4 && p.B > 0 && p.T > 0 && plain_format(p);
+  return (p.align_bits & 15) == 0 && p.wrt == 0 && (p.V == 256 || p.V == 512 || p.V == 1024) && L.NL <= 4 && p.B > 0 && p.T > 0 && plain_format(p);
 }
 inline hipError_t run_fused(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
   return p.kind == 0 ? run_fused_classic(p, L, ws, loss, d_loss, grad, st) : run_fused_simplified(p, L, ws, loss, d_loss, grad, st);
@@ -67,6 +67,8 @@ size_t hvp_extra_bytes(int kind, int B, int T, int V, int U);
 int g_force_pipeline = 0;      // 0 = best eligible tier, 1 = v1, 2 = fused2, 5 = fused5 (log domain)
 int g_force_hessian_slab = 0;  // 1 = the general one-slab-per-wavefront Hessian kernel also for short labels
 hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec, float *out, hipStream_t st);
+hipError_t run_check_labels(const int32_t *labels, int label_stride, const int32_t *label_length, int blank, int B, int V, int U,
+                            int *bad, hipStream_t st);
 }  // namespace ctc
 
 namespace {
@@ -81,8 +83,10 @@ int fail(int code, const char *fmt, ...) {
   return code;
 }
 
-constexpr int MAX_U = 16 * 64;       // scan_kernel is instantiated for up to 16 label positions per lane
-constexpr int MAX_V_GRAD = 16 * 1024;  // one LDS token row per wavefront
+// Limits (include/ctc_amd.h "Limits"): CTC_AMD_EINVAL beyond them
+constexpr int MAX_U = CTC_AMD_MAX_U;            // scan_kernel is instantiated for up to 16 label positions per lane
+constexpr int MAX_V_GRAD = CTC_AMD_MAX_V;       // one LDS token row per wavefront (64 KB)
+constexpr int MAX_V_HESS = CTC_AMD_MAX_V_HESSIAN;  // the Hessian / HVP kernels keep V + 4 floats of LDS per wavefront
 
 int check_common(int kind, int wrt, const float *logits, const int32_t *labels, int label_stride,
                  const int32_t *label_length, const int32_t *logit_length, int blank, int B, int T, int V, int U) {
@@ -155,6 +159,25 @@ const char *ctc_amd_pipeline_name(int kind, int wrt, int B, int T, int V, int U,
   return select_pipeline(p, L, want_grad != 0);
 }
 
+int ctc_amd_check_labels(const int32_t *labels, int label_stride, const int32_t *label_length, int blank_index, int B, int V,
+                         int U, void *stream) {
+  if (B < 0 || V <= 0 || U < 0 || label_stride < 0) return fail(CTC_AMD_EINVAL, "negative size");
+  if (B == 0 || label_stride == 0) return CTC_AMD_OK;
+  if (!labels || !label_length) return fail(CTC_AMD_EINVAL, "null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int *bad = nullptr;
+  hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&bad), sizeof(int), st);
+  if (e != hipSuccess) return hip_fail(e, "hipMallocAsync");
+  e = ctc::run_check_labels(labels, label_stride, label_length, blank_index, B, V, U, bad, st);
+  int host = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&host, bad, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  hipFreeAsync(bad, st);
+  if (e != hipSuccess) return hip_fail(e, "label check");
+  if (host != 0) return fail(CTC_AMD_ELABEL, "%d label(s) inside label_length are outside [0, %d) or equal to blank_index %d", host, V, blank_index);
+  return CTC_AMD_OK;
+}
+
 int ctc_amd_workspace_bytes(int what, int kind, int B, int T, int V, int U, size_t *out_bytes) {
   if (!out_bytes) return fail(CTC_AMD_EINVAL, "out_bytes is null");
   if (kind != 0 && kind != 1) return fail(CTC_AMD_EINVAL, "bad kind %d", kind);
@@ -175,6 +198,7 @@ static int loss_grad_impl(ctc::Problem p, float *loss, void *grad, const float *
   if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
   hipStream_t st = static_cast<hipStream_t>(stream);
   float *gradf = static_cast<float *>(grad);  // element-typed inside the kernels (Problem::gdtype)
+  p.align_bits = (int)((reinterpret_cast<uintptr_t>(p.logits) | reinterpret_cast<uintptr_t>(grad)) & 15);
   const char *pl = select_pipeline(p, L, grad != nullptr);
   if (pl[0] == 'f') {
     char *wsb = static_cast<char *>(workspace);
@@ -226,6 +250,30 @@ int ctc_amd_loss_grad_ex(int kind, int wrt, const void *logits, int logits_dtype
   return loss_grad_impl(p, loss, grad, d_loss, workspace, workspace_bytes, stream);
 }
 
+int ctc_amd_grad_resume(int kind, int wrt, const void *logits, int logits_dtype, int64_t logits_stride_b,
+                        int64_t logits_stride_t, const int32_t *labels, int label_stride, const int32_t *label_length,
+                        const int32_t *logit_length, int blank_index, int B, int T, int V, int U, float *loss, void *grad,
+                        int grad_dtype, int64_t grad_stride_b, int64_t grad_stride_t, const float *d_loss, void *workspace,
+                        size_t workspace_bytes, void *stream) {
+  int rc = check_common(kind, wrt, static_cast<const float *>(logits), labels, label_stride, label_length, logit_length,
+                        blank_index, B, T, V, U);
+  if (rc) return rc;
+  if ((logits_dtype != CTC_AMD_F32 && logits_dtype != CTC_AMD_BF16) || (grad_dtype != CTC_AMD_F32 && grad_dtype != CTC_AMD_BF16))
+    return fail(CTC_AMD_EINVAL, "dtype must be CTC_AMD_F32 or CTC_AMD_BF16 (logits %d, grad %d)", logits_dtype, grad_dtype);
+  if (!grad) return fail(CTC_AMD_EINVAL, "null grad pointer");
+  if (B == 0) return CTC_AMD_OK;
+  if (logits_stride_t < V || logits_stride_b < V || grad_stride_t < V || grad_stride_b < V)
+    return fail(CTC_AMD_EINVAL, "strides smaller than a row of V=%d elements", V);
+  ctc::Problem p = make_problem(kind, wrt, static_cast<const float *>(logits), labels, label_stride, label_length, logit_length,
+                                blank_index, B, T, V, U);
+  p.xsb = logits_stride_b; p.xst = logits_stride_t; p.xdtype = logits_dtype;
+  p.gsb = grad_stride_b; p.gst = grad_stride_t; p.gdtype = grad_dtype;
+  // only the linear-domain fused kernel keeps what the second half needs; every other pipeline computes loss and gradient anew
+  ctc::Layout L = ctc::make_layout(p.kind, p.B, p.T, p.U, 0);
+  if (!strcmp(select_pipeline(p, L, true), "fused6")) p.resume = 1;
+  return loss_grad_impl(p, loss, grad, d_loss, workspace, workspace_bytes, stream);
+}
+
 int ctc_amd_alpha_beta(int kind, int wrt, const float *logits, const int32_t *labels, int label_stride,
                        const int32_t *label_length, const int32_t *logit_length, int blank_index, int B, int T, int V,
                        int U, float *loss, float *alpha, float *beta, void *workspace, size_t workspace_bytes,
@@ -253,7 +301,7 @@ int ctc_amd_hessian(int kind, int wrt, const float *logits, const int32_t *label
   if (rc) return rc;
   if (B == 0) return CTC_AMD_OK;
   if (!loss || !hess) return fail(CTC_AMD_EINVAL, "null output pointer");
-  if (V > MAX_V_GRAD) return fail(CTC_AMD_EINVAL, "V=%d exceeds the supported maximum %d", V, MAX_V_GRAD);
+  if (V > MAX_V_HESS) return fail(CTC_AMD_EINVAL, "V=%d exceeds the supported maximum %d of the Hessian", V, MAX_V_HESS);
   ctc::Layout L = ctc::make_layout(kind, B, T, U, ctc::hessian_extra_bytes(kind, B, T, V, U));
   if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
   ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
@@ -285,7 +333,7 @@ int ctc_amd_hvp(int kind, int wrt, const float *logits, const int32_t *labels, i
   if (rc) return rc;
   if (B == 0) return CTC_AMD_OK;
   if (!loss || !out || (T > 0 && !vec)) return fail(CTC_AMD_EINVAL, "null vec/output pointer");
-  if (V > MAX_V_GRAD) return fail(CTC_AMD_EINVAL, "V=%d exceeds the supported maximum %d", V, MAX_V_GRAD);
+  if (V > MAX_V_HESS) return fail(CTC_AMD_EINVAL, "V=%d exceeds the supported maximum %d of the Hessian-vector product", V, MAX_V_HESS);
   ctc::Layout L = ctc::make_layout(kind, B, T, U, ctc::hvp_extra_bytes(kind, B, T, V, U));
   if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
   ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);

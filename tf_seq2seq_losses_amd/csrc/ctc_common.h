@@ -62,6 +62,12 @@ struct Problem {
   // as contiguous float32 [B,T,V].
   long xsb, xst, gsb, gst;
   int xdtype, gdtype;
+  // 1: second half of a two-call loss -> gradient sequence (ctc_amd_grad_resume): the workspace still holds what the
+  // loss-only call left (checkpoints, softmax statistics, log P, flags); only the linear-domain fused kernel uses it
+  int resume = 0;
+  // low 4 bits of (logits pointer | gradient pointer): the 16-byte (float32) / 8-byte (bfloat16) row accesses of the fast
+  // paths need aligned bases as well as aligned strides; otherwise the element-wise paths run
+  int align_bits = 0;
 };
 
 // bfloat16 <-> float32 (round to nearest even on the way back)
@@ -90,7 +96,7 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
 //   logp  [B] double       : log2 P(label | logits), -inf when infeasible
 struct Layout {
   int NL, UP, ERS, SRS;
-  size_t off_emis, off_alpha, off_beta, off_logp, off_dummy, off_perm, off_kexp, off_flags, off_extra, total;
+  size_t off_emis, off_alpha, off_beta, off_logp, off_dummy, off_perm, off_kexp, off_flags, off_meet, off_extra, total;
 };
 
 inline int nl_for(int U) {
@@ -117,6 +123,7 @@ inline Layout make_layout(int kind, int B, int T, int U, size_t extra_bytes) {
   // per-utterance flags that send an utterance to the log-domain kernel
   L.off_kexp = o;  o = al(o + (size_t)B * 2 * ((T + 5) / 6 + 3) * 64 * 4);
   L.off_flags = o; o = al(o + (size_t)B * 4 + (size_t)B * 2048 * 4);  // (+ 8 KB per utterance for diagnostic builds)
+  L.off_meet = o;  o = al(o + (size_t)B * 8);  // per utterance: posterior scale (integer exponent, mantissa factor) from the meeting point
   L.off_extra = o; o = al(o + extra_bytes);
   L.total = o;
   return L;

@@ -845,12 +845,13 @@ template <int NL, int NH, int BLK, int VPL>
 static hipError_t launch5(const Problem &p, const Layout &L, float *a, float *b, double *lp, float2 *stats, float *loss,
                           const float *d_loss, float *grad, void *stamp, const int *perm, const int *only_if, hipStream_t st) {
   static_assert(sizeof(fused5::Lds<CTC_FUSED_KIND, NL, NH, BLK, VPL>) <= 160 * 1024, "LDS budget of one CU");
-  const bool plain = p.xdtype == 0 && p.V == 256 * VPL && p.xst == p.V && p.gst == p.V;  // frame stride folded into the addressing
+  const bool al16 = (p.align_bits & 15) == 0;  // 16-byte row accesses need aligned base pointers as well as strides
+  const bool plain = al16 && p.xdtype == 0 && p.V == 256 * VPL && p.xst == p.V && p.gst == p.V;  // frame stride folded into the addressing
   const dim3 grid(p.B), block(64 * (4 + 2 * NH));
   if (plain)
     hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 0>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
                        d_loss, grad, stamp, perm, only_if);
-  else if (p.xdtype == 0 && ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0)
+  else if (al16 && p.xdtype == 0 && ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0)
     hipLaunchKernelGGL((fused5::fused5_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 1>), grid, block, 0, st, p, L, a, b, lp, stats, loss,
                        d_loss, grad, stamp, perm, only_if);
   else if (p.xdtype == 0)  // vocabulary or strides not a multiple of 4 elements: element-wise row accesses

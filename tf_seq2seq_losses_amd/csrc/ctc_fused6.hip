@@ -365,10 +365,13 @@ struct Chain {
     kn = imax(kn, DEAD);
     const int d = k - kn;
     // D3: own live values crushed by a much larger inflow scale; D4: decayed by more than 2^-DECAY_MAX, or live -> zero
-    flag |= (live && d < -DOWN_MAX ? 4 : 0) | (live && fe < -DECAY_MAX ? 8 : 0) | (!live && alive ? 16 : 0);
+    // (D3 only for a lane that has had mass for a few periods: at the lattice front the first thin paths of a lane are
+    // legitimately swamped when the bulk arrives, ~1 in 256 benign utterances)
+    age = (live && alive) ? age + 1 : 0;
+    flag |= (live && age >= 3 && d < -DOWN_MAX ? 4 : 0) | (live && fe < -DECAY_MAX ? 8 : 0) | (!live && alive ? 16 : 0);
 #ifdef CTC_F6_DEBUG
     ++cnt;
-    if (!live && alive && dbg0 == 0) { dbg0 = cnt; dbg1 = k; dbg2 = __float_as_int(mlast); }
+    if (live && d < -DOWN_MAX && dbg0 == 0) { dbg0 = cnt; dbg1 = d; dbg2 = fe; }
     mlast = m;
 #endif
 #pragma unroll
@@ -383,6 +386,7 @@ struct Chain {
     alive = live;
   }
   bool alive = false;  // the lane had mass at its last renormalisation
+  int age = 0;         // consecutive renormalisations with mass
   bool relevant = true;
 #ifdef CTC_F6_DEBUG
   int cnt = 0, dbg0 = 0, dbg1 = 0, dbg2 = 0;
@@ -706,7 +710,7 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL, VPL, XT> &S, Lds<KI
 template <int KIND, int NL, int NH, int BLK, int VPL, int DIR>
 __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, float *__restrict__ alpha_ws,
                                          float *__restrict__ beta_ws, int *__restrict__ kexp_ws, double *__restrict__ logp_ws,
-                                         float *__restrict__ loss, int *__restrict__ flag_ws,
+                                         float *__restrict__ loss, int *__restrict__ flag_ws, int2 *__restrict__ meet_ws,
                                          Lds<KIND, NL, NH, BLK, VPL> &lds, const Geo<BLK> &geo, bool want_grad, int b) {
   using LD = Lds<KIND, NL, NH, BLK, VPL>;
   using CD = Cad<BLK, NL>;
@@ -731,6 +735,12 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
   (void)flag_ws_dbg;
   F6_STAMP_DECL
 
+  if (p.resume) {
+    // second call of a loss -> gradient pair: this chain continues from its own row at the meeting point
+    CkRow<KIND, NL> r;
+    load_ck<KIND, NL>(r, own_rows, own_k, geo.slot(geo.tm), SRS, UP, lane);
+    restore<KIND, NL, DIR>(S, r);
+  } else {
   // ================= phase 1: lattice steps, one checkpoint row per block =================
   {
     const int nb = geo.nblocks(1, DIR);
@@ -817,9 +827,11 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
       lds.cf = __builtin_amdgcn_rcpf(ldexp_f(s, -fe));   // 1 / mantissa, in (1, 2]
       lds.feasible = (fl == 0);
       lds.flag = fl;
+      meet_ws[b] = make_int2(EX + fe, __float_as_int(lds.cf));
     }
   }
   __syncthreads();
+  }  // !resume
   const bool go = lds.feasible != 0;
   if (!want_grad || !go) {  // loss only, or flagged (the log-domain kernel redoes this utterance): every role leaves here
     if (DIR == 0 && lane == 0) flag_ws[b] = lds.flag;
@@ -996,7 +1008,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
   const int *ck_k = kexp_ws + ((long)b * 2 + RDIR) * nslot * 64;
   float *dump = lds.dump[2 + SIDE];
 
-  {  // phase 1: nothing to recompute yet -- this wavefront works the E stage of its side
+  if (!p.resume) {  // phase 1: nothing to recompute yet -- this wavefront works the E stage of its side
     using SP = P1Split<BLK, NH, NL>;
     Rows<KIND, NL, VPL, XT> W;
     W.init(p, b, lane, ll, nullptr, nullptr);
@@ -1004,9 +1016,9 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
     if (lane == 0) W.xs[256 * VPL] = 0.f;  // pad slot of the gather copy: emission 0 for label positions beyond label_length
     float2 *stats = stats_ws + (long)b * T;
     estage1<KIND, NL, NH, BLK, VPL, XT, SIDE, SP::first(NH), SP::count(NH)>(W, lds, geo, stats, dump, lane, 2 + SIDE F6_ST_ARG);
+    __syncthreads();
+    __syncthreads();
   }
-  __syncthreads();
-  __syncthreads();
   if (!want_grad || lds.feasible == 0) return;
   F6_STAMP_PHASE2
 
@@ -1136,7 +1148,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
   };
 
   // ================= phase 1: E stage with statistics =================
-  {
+  if (!p.resume) {
     using SP = P1Split<BLK, NH, NL>;
     if constexpr (NH == 4) {
       switch (h) {
@@ -1149,11 +1161,10 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
       if (h == 0) estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, dump, lane, wave F6_ST_ARG);
       else estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(1), SP::count(1)>(S, lds, geo, stats, dump, lane, wave F6_ST_ARG);
     }
+    // ================= meeting point =================
+    __syncthreads();
+    __syncthreads();
   }
-
-  // ================= meeting point =================
-  __syncthreads();
-  __syncthreads();
   if (grad == nullptr || lds.feasible == 0) return;  // loss only / flagged
   F6_STAMP_PHASE2
 
@@ -1324,21 +1335,28 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused6_kernel(Problem p, La
                                                                     float *__restrict__ loss,
                                                                     const float *__restrict__ d_loss,
                                                                     float *__restrict__ grad, int *__restrict__ flag_ws,
-                                                                    const int *__restrict__ perm) {
+                                                                    int2 *__restrict__ meet_ws, const int *__restrict__ perm) {
   __shared__ __attribute__((aligned(16))) Lds<KIND, NL, NH, BLK, VPL> lds;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = perm ? perm[blockIdx.x] : (int)blockIdx.x;
   Geo<BLK> geo;
   geo.init(clampi(p.logit_length[b], 0, p.T));
-  if (threadIdx.x == 0) { lds.flag = 0; lds.feasible = 0; }
+  if (threadIdx.x == 0) {
+    lds.flag = 0; lds.feasible = 0;
+    if (p.resume) {  // the loss-only call left the outcome of the meeting point in the workspace
+      const int f = flag_ws[b];
+      const int2 m = meet_ws[b];
+      lds.flag = f; lds.feasible = (f == 0); lds.lp_int = m.x; lds.cf = __int_as_float(m.y);
+    }
+  }
   if (threadIdx.x < Lds<KIND, NL, NH, BLK, VPL>::NW) lds.l2s[threadIdx.x] = 0.0;
   __syncthreads();
   if (w == 0) {
     __builtin_amdgcn_s_setprio(3);
-    run_main<KIND, NL, NH, BLK, VPL, 0>(p, L, alpha_ws, beta_ws, kexp_ws, logp_ws, loss, flag_ws, lds, geo, grad != nullptr, b);
+    run_main<KIND, NL, NH, BLK, VPL, 0>(p, L, alpha_ws, beta_ws, kexp_ws, logp_ws, loss, flag_ws, meet_ws, lds, geo, grad != nullptr, b);
   } else if (w == 1) {
     __builtin_amdgcn_s_setprio(3);
-    run_main<KIND, NL, NH, BLK, VPL, 1>(p, L, alpha_ws, beta_ws, kexp_ws, logp_ws, loss, flag_ws, lds, geo, grad != nullptr, b);
+    run_main<KIND, NL, NH, BLK, VPL, 1>(p, L, alpha_ws, beta_ws, kexp_ws, logp_ws, loss, flag_ws, meet_ws, lds, geo, grad != nullptr, b);
   } else if (w == 2) {
     __builtin_amdgcn_s_setprio(2);
     run_recompute<KIND, NL, NH, BLK, VPL, 0, XT>(p, L, alpha_ws, beta_ws, kexp_ws, stats_ws, lds, geo, grad != nullptr, b, flag_ws);
@@ -1356,22 +1374,23 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused6_kernel(Problem p, La
 
 template <int NL, int NH, int BLK, int VPL>
 static hipError_t launch6(const Problem &p, const Layout &L, float *a, float *b, int *kexp, double *lp, float2 *stats, float *loss,
-                          const float *d_loss, float *grad, int *flags, const int *perm, hipStream_t st) {
+                          const float *d_loss, float *grad, int *flags, int2 *meet, const int *perm, hipStream_t st) {
   static_assert(sizeof(fused6::Lds<CTC_FUSED_KIND, NL, NH, BLK, VPL>) <= 160 * 1024, "LDS budget of one CU");
-  const bool plain = p.xdtype == 0 && p.V == 256 * VPL && p.xst == p.V && p.gst == p.V;
+  const bool al16 = (p.align_bits & 15) == 0;  // 16-byte row accesses need aligned base pointers as well as strides
+  const bool plain = al16 && p.xdtype == 0 && p.V == 256 * VPL && p.xst == p.V && p.gst == p.V;
   const dim3 grid(p.B), block(64 * (4 + 2 * NH));
   if (plain)
     hipLaunchKernelGGL((fused6::fused6_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 0>), grid, block, 0, st, p, L, a, b, kexp, lp, stats, loss,
-                       d_loss, grad, flags, perm);
-  else if (p.xdtype == 0 && ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0)
+                       d_loss, grad, flags, meet, perm);
+  else if (al16 && p.xdtype == 0 && ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0)
     hipLaunchKernelGGL((fused6::fused6_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 1>), grid, block, 0, st, p, L, a, b, kexp, lp, stats, loss,
-                       d_loss, grad, flags, perm);
+                       d_loss, grad, flags, meet, perm);
   else if (p.xdtype == 0)
     hipLaunchKernelGGL((fused6::fused6_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 3>), grid, block, 0, st, p, L, a, b, kexp, lp, stats, loss,
-                       d_loss, grad, flags, perm);
+                       d_loss, grad, flags, meet, perm);
   else
     hipLaunchKernelGGL((fused6::fused6_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 2>), grid, block, 0, st, p, L, a, b, kexp, lp, stats, loss,
-                       d_loss, grad, flags, perm);
+                       d_loss, grad, flags, meet, perm);
   return hipGetLastError();
 }
 
@@ -1397,6 +1416,7 @@ hipError_t CTC_F6_ENTRY(const Problem &p, const Layout &L, char *ws, float *loss
   float2 *stats = reinterpret_cast<float2 *>(ws + L.off_emis);  // the emission region of the v1 pipeline is free here
   int *kexp = reinterpret_cast<int *>(ws + L.off_kexp);
   int *flags = reinterpret_cast<int *>(ws + L.off_flags);
+  int2 *meet = reinterpret_cast<int2 *>(ws + L.off_meet);
   if (L.NL != CTC_FUSED6_NL) return hipErrorInvalidValue;
   // more utterances than CUs: longest first (one small kernel; skipped for batches that fit the chip in one go)
   const int *perm = nullptr;
@@ -1406,12 +1426,12 @@ hipError_t CTC_F6_ENTRY(const Problem &p, const Layout &L, char *ws, float *loss
     perm = reinterpret_cast<const int *>(ws + L.off_perm);
   }
 #if CTC_FUSED6_NL == 4
-  return p.V <= 256 ? launch6<4, 2, 6, 1>(p, L, alpha, beta, kexp, logp, stats, loss, d_loss, grad, flags, perm, st)
-                    : launch6<4, 2, 6, 2>(p, L, alpha, beta, kexp, logp, stats, loss, d_loss, grad, flags, perm, st);
+  return p.V <= 256 ? launch6<4, 2, 6, 1>(p, L, alpha, beta, kexp, logp, stats, loss, d_loss, grad, flags, meet, perm, st)
+                    : launch6<4, 2, 6, 2>(p, L, alpha, beta, kexp, logp, stats, loss, d_loss, grad, flags, meet, perm, st);
 #else
-  return p.V <= 256   ? launch6<CTC_FUSED6_NL, 4, 12, 1>(p, L, alpha, beta, kexp, logp, stats, loss, d_loss, grad, flags, perm, st)
-         : p.V <= 512 ? launch6<CTC_FUSED6_NL, 2, 6, 2>(p, L, alpha, beta, kexp, logp, stats, loss, d_loss, grad, flags, perm, st)
-                      : launch6<CTC_FUSED6_NL, 2, 6, 4>(p, L, alpha, beta, kexp, logp, stats, loss, d_loss, grad, flags, perm, st);
+  return p.V <= 256   ? launch6<CTC_FUSED6_NL, 4, 12, 1>(p, L, alpha, beta, kexp, logp, stats, loss, d_loss, grad, flags, meet, perm, st)
+         : p.V <= 512 ? launch6<CTC_FUSED6_NL, 2, 6, 2>(p, L, alpha, beta, kexp, logp, stats, loss, d_loss, grad, flags, meet, perm, st)
+                      : launch6<CTC_FUSED6_NL, 2, 6, 4>(p, L, alpha, beta, kexp, logp, stats, loss, d_loss, grad, flags, meet, perm, st);
 #endif
 }
 

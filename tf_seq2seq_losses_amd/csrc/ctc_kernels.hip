@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void emit_kernel(Problem p, Layout L, float *_
 
   float mx = -INFINITY, sum = 0.f, log2sum = 0.f;
   if (p.wrt == 0) {
-    if (!bf && ((V | xoff) & 3) == 0) {
+    if (!bf && ((V | xoff) & 3) == 0 && (p.align_bits & 15) == 0) {
       for (int k = lane * 4; k < V; k += 256) {
         float4 v = *reinterpret_cast<const float4 *>(x + k);
         mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256) void emit_kernel(Problem p, Layout L, float *_
     float e = NEG;
     if (i < ll) {
       int tok = (i < p.label_stride) ? p.labels[(long)b * p.label_stride + i] : p.blank;
-      if (tok >= 0 && tok < V) e = fmaxf((xat(tok) - mx) * LOG2E - log2sum, NEG);
+      // (a label equal to the blank id is unsupported input in the reference; every tier treats it as an impossible
+      // emission: the sample comes out infeasible, loss +inf, gradient 0)
+      if (tok >= 0 && tok < V && tok != p.blank) e = fmaxf((xat(tok) - mx) * LOG2E - log2sum, NEG);
       if (!(e == e)) e = NEG;
     }
     erow[i] = e;
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
     v4f v = {r.x, r.y, r.z, r.w};
     __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(g + k));
   };
-  const bool gvec = !gbf && ((V | goff) & 3) == 0;
+  const bool gvec = !gbf && ((V | goff) & 3) == 0 && (p.align_bits & 15) == 0;
   const int len = clampi(p.logit_length[b], 0, p.T);
   const double lp = logp[b];
   if (t >= len || lp == -INFINITY) {
@@ -651,6 +653,33 @@ static __global__ __launch_bounds__(256) void order_kernel(const int *__restrict
 hipError_t run_order(const Problem &p, const Layout &L, char *ws, hipStream_t st) {
   int *perm = reinterpret_cast<int *>(ws + L.off_perm);
   hipLaunchKernelGGL(order_kernel, dim3((p.B + 255) / 256), dim3(256), 0, st, p.logit_length, p.B, p.T, perm);
+  return hipGetLastError();
+}
+
+// labels[b][i] for i < min(label_length[b], U, label_stride) must lie in [0, V) and differ from the blank: counts the offenders
+static __global__ __launch_bounds__(256) void check_labels_kernel(const int32_t *__restrict__ labels, int label_stride,
+                                                                  const int32_t *__restrict__ label_length, int blank, int B, int V,
+                                                                  int U, int *__restrict__ bad) {
+  const long n = (long)B * label_stride;
+  int mine = 0;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int b = (int)(idx / label_stride), i = (int)(idx % label_stride);
+    int ll = label_length[b];
+    ll = ll > U ? 0 : ll;  // (such a sample is infeasible by definition; its labels are never read)
+    if (i < ll) {
+      const int tk = labels[idx];
+      mine += (tk < 0 || tk >= V || tk == blank);
+    }
+  }
+  if (mine) atomicAdd(bad, mine);
+}
+hipError_t run_check_labels(const int32_t *labels, int label_stride, const int32_t *label_length, int blank, int B, int V, int U,
+                            int *bad, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(bad, 0, sizeof(int), st);
+  if (e != hipSuccess) return e;
+  const long n = (long)B * label_stride;
+  const unsigned blocks = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  hipLaunchKernelGGL(check_labels_kernel, dim3(blocks), dim3(256), 0, st, labels, label_stride, label_length, blank, B, V, U, bad);
   return hipGetLastError();
 }
 

@@ -82,24 +82,17 @@ class _HessianContraction(torch.autograd.Function):
         raise NotImplementedError("Third order derivative over the ctc loss function is not implemented.")
 
 
-# When the logits require a gradient the forward pass produces loss AND unit gradient in ONE kernel launch (the gradient
-# costs the kernel nothing extra to speak of: it is the second half of the same launch) and backward only rescales it.
-# The [B,T,V] gradient is kept alive between forward and backward, like the activations it belongs to; a caller that
-# cannot afford that (it is 0.1 % of the HBM at the north-star size) sets EAGER_GRADIENT_MAX_ELEMENTS lower: above the
-# limit forward computes the loss only and backward runs the kernel again with d_loss applied inside it.
-EAGER_GRADIENT_MAX_ELEMENTS = 1 << 40
-
-
 class _CtcGradient(torch.autograd.Function):
     """gradient_fn (base_loss.py:157-175) composed with forward_fn.backprop (base_loss.py:150-153):
     returns d_loss[:,None,None] * gradient and differentiates to the Hessian contraction."""
 
     @staticmethod
-    def forward(ctx, x, d_loss, kind, wrt, prep, grad_unit):
+    def forward(ctx, x, d_loss, kind, wrt, prep, pending):
         ctx.kind, ctx.wrt, ctx.prep = kind, wrt, prep
         ctx.save_for_backward(x, d_loss)
-        if grad_unit is not None:
-            return (d_loss.reshape(-1, 1, 1) * grad_unit).to(grad_unit.dtype)
+        if pending is not None:  # the forward pass left its half of the work in a workspace: run the other half (one launch)
+            loss, ws = pending
+            return ops.grad_resume(kind, wrt, prep, loss, ws, d_loss=d_loss)
         return ops.loss_grad(kind, wrt, prep, True, d_loss=d_loss)[1]  # weighting inside the kernel
 
     @staticmethod
@@ -115,26 +108,27 @@ class _CtcGradient(torch.autograd.Function):
 
 
 class _CtcLoss(torch.autograd.Function):
-    """forward_fn (base_loss.py:140-155).  Small problems: loss and unit gradient from ONE kernel pipeline, the gradient
-    kept for backward.  Large problems: the loss only (the fused kernel stops where its two chains meet); the gradient is
-    computed when -- and if -- backward asks for it, already weighted by d_loss."""
+    """forward_fn (base_loss.py:140-155).  The forward pass runs the first half of the fused kernel (both lattice chains up
+    to their meeting point: the loss) and keeps its workspace; backward runs the second half from there with d_loss applied
+    inside the kernel -- together one loss+gradient call's work, no [B,T,V] tensor kept alive in between, no extra pass
+    over the gradient for the d_loss weights (ctc_amd_grad_resume)."""
 
     @staticmethod
     def forward(ctx, x, kind, wrt, prep):
-        eager = x.requires_grad and x.numel() <= EAGER_GRADIENT_MAX_ELEMENTS
-        loss, grad = ops.loss_grad(kind, wrt, prep, want_grad=eager)
         ctx.kind, ctx.wrt, ctx.prep = kind, wrt, prep
-        if eager:
-            ctx.save_for_backward(x, grad)
+        ctx.save_for_backward(x)
+        if x.requires_grad:
+            loss, ws = ops.loss_forward(kind, wrt, prep)
+            ctx.pending = (loss.detach(), ws)  # (an alias without autograd history: no reference cycle through ctx)
         else:
-            ctx.save_for_backward(x)
+            loss = ops.loss_grad(kind, wrt, prep, want_grad=False)[0]
+            ctx.pending = None
         return loss
 
     @staticmethod
     def backward(ctx, d_loss):
         x = ctx.saved_tensors[0]
-        grad_unit = ctx.saved_tensors[1] if len(ctx.saved_tensors) > 1 else None
-        return _CtcGradient.apply(x, d_loss, ctx.kind, ctx.wrt, ctx.prep, grad_unit), None, None, None
+        return _CtcGradient.apply(x, d_loss, ctx.kind, ctx.wrt, ctx.prep, ctx.pending), None, None, None
 
 
 def _ctc(kind_name: str, wrt: int, labels, x, label_length, logit_length, blank_index) -> torch.Tensor:

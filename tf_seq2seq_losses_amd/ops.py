@@ -40,10 +40,12 @@ class Prepared:
         native = (keep_format and x.dim() == 3 and x.dtype in _DTYPES and x.numel() > 0 and x.stride(2) == 1
                   and x.stride(0) >= V and x.stride(1) >= V)
         self.native = bool(native) and not (x.dtype == torch.float32 and x.is_contiguous())
-        self.x = x if native else x.to(torch.float32).contiguous()
-        self.labels = labels.to(device=dev, dtype=torch.int32).contiguous()
-        self.label_length = label_length.to(device=dev, dtype=torch.int32).contiguous()
-        self.logit_length = logit_length.to(device=dev, dtype=torch.int32).contiguous()
+        self.x = x if (native or (x.dtype == torch.float32 and x.is_contiguous())) else x.to(torch.float32).contiguous()
+        def i32(t):
+            if t.dtype == torch.int32 and t.device == dev and t.is_contiguous():
+                return t
+            return t.to(device=dev, dtype=torch.int32).contiguous()
+        self.labels, self.label_length, self.logit_length = i32(labels), i32(label_length), i32(logit_length)
         self.blank = int(blank_index)
         self.B, self.T, self.V = (int(s) for s in x.shape)
         self.stride = int(self.labels.shape[1])
@@ -99,6 +101,24 @@ def _stream(dev) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+class _on_device:
+    """`with torch.cuda.device(dev)` costs ~10 us of host time per call; most calls already run on the right device."""
+
+    __slots__ = ("dev", "ctx")
+
+    def __init__(self, dev):
+        self.dev, self.ctx = dev, None
+
+    def __enter__(self):
+        if self.dev.index is not None and torch.cuda.current_device() != self.dev.index:
+            self.ctx = torch.cuda.device(self.dev)
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
 def loss_grad(kind: int, wrt: int, p: Prepared, want_grad: bool, d_loss: Optional[torch.Tensor] = None,
               workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     lib = _lib.load()
@@ -112,7 +132,7 @@ def loss_grad(kind: int, wrt: int, p: Prepared, want_grad: bool, d_loss: Optiona
     ws = workspace if workspace is not None else _workspace(_lib.WS_LOSS_GRAD, kind, p)
     if d_loss is not None:
         d_loss = d_loss.to(device=p.device, dtype=torch.float32).contiguous()
-    with torch.cuda.device(p.device):
+    with _on_device(p.device):
         if p.native:
             dt = _DTYPES[p.x.dtype]
             rc = lib.ctc_amd_loss_grad_ex(kind, wrt, _ptr(p.x), dt, p.x.stride(0), p.x.stride(1), _ptr(p.labels), p.stride,
@@ -126,6 +146,38 @@ def loss_grad(kind: int, wrt: int, p: Prepared, want_grad: bool, d_loss: Optiona
     return loss, grad
 
 
+def loss_forward(kind: int, wrt: int, p: Prepared) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Loss only, with a workspace of its own that grad_resume continues from (returned; keep it alive until then)."""
+    n = _WS_BYTES.get((_lib.WS_LOSS_GRAD, kind, p.B, p.T, p.V, p.U))
+    if n is None:
+        n = _WS_BYTES[(_lib.WS_LOSS_GRAD, kind, p.B, p.T, p.V, p.U)] = _lib.workspace_bytes(_lib.WS_LOSS_GRAD, kind, p.B, p.T, p.V, p.U)
+    ws = torch.empty(max(n, 1), dtype=torch.uint8, device=p.device)
+    loss, _ = loss_grad(kind, wrt, p, False, workspace=ws)
+    return loss, ws
+
+
+def grad_resume(kind: int, wrt: int, p: Prepared, loss: torch.Tensor, ws: torch.Tensor,
+                d_loss: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Gradient for the loss that loss_forward computed into `ws` (ctc_amd_grad_resume), weighted by d_loss."""
+    lib = _lib.load()
+    if p.native:
+        grad = torch.empty_strided(p.x.shape, p.x.stride(), dtype=p.x.dtype, device=p.device)
+    else:
+        grad = torch.empty((p.B, p.T, p.V), dtype=torch.float32, device=p.device)
+    if p.B == 0 or p.T == 0:
+        return grad
+    if d_loss is not None:
+        d_loss = d_loss.to(device=p.device, dtype=torch.float32).contiguous()
+    dt = _DTYPES[p.x.dtype]
+    with _on_device(p.device):
+        rc = lib.ctc_amd_grad_resume(kind, wrt, _ptr(p.x), dt, p.x.stride(0), p.x.stride(1), _ptr(p.labels), p.stride,
+                                     _ptr(p.label_length), _ptr(p.logit_length), p.blank, p.B, p.T, p.V, p.U,
+                                     _ptr(loss), _ptr(grad), dt, grad.stride(0), grad.stride(1), _ptr(d_loss),
+                                     ws.data_ptr(), ws.numel(), _stream(p.device))
+    _lib.check(rc, "ctc_amd_grad_resume")
+    return grad
+
+
 def alpha_beta(kind: int, wrt: int, p: Prepared):
     lib = _lib.load()
     p = p.plain()
@@ -137,7 +189,7 @@ def alpha_beta(kind: int, wrt: int, p: Prepared):
     if p.B == 0:
         return loss, alpha, beta
     ws = _workspace(_lib.WS_ALPHA_BETA, kind, p)
-    with torch.cuda.device(p.device):
+    with _on_device(p.device):
         rc = lib.ctc_amd_alpha_beta(*p.common(kind, wrt), _ptr(loss), _ptr(alpha), _ptr(beta),
                                     ws.data_ptr(), ws.numel(), _stream(p.device))
     _lib.check(rc, "ctc_amd_alpha_beta")
@@ -155,7 +207,7 @@ def hessian(kind: int, wrt: int, p: Prepared, want_grad: bool = True):
             loss, _ = loss_grad(kind, wrt, p, False)
         return loss, grad, hess
     ws = _workspace(_lib.WS_HESSIAN, kind, p)
-    with torch.cuda.device(p.device):
+    with _on_device(p.device):
         rc = lib.ctc_amd_hessian(*p.common(kind, wrt), _ptr(loss), _ptr(grad), _ptr(hess),
                                  ws.data_ptr(), ws.numel(), _stream(p.device))
     _lib.check(rc, "ctc_amd_hessian")
@@ -176,7 +228,7 @@ def hvp(kind: int, wrt: int, p: Prepared, vec: torch.Tensor, want_grad: bool = F
             loss, _ = loss_grad(kind, wrt, p, False)
         return loss, grad, out
     ws = _workspace(_lib.WS_HVP, kind, p)
-    with torch.cuda.device(p.device):
+    with _on_device(p.device):
         rc = lib.ctc_amd_hvp(*p.common(kind, wrt), _ptr(vec), _ptr(loss), _ptr(grad), _ptr(out),
                              ws.data_ptr(), ws.numel(), _stream(p.device))
     _lib.check(rc, "ctc_amd_hvp")
