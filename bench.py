@@ -298,16 +298,13 @@ def main():
                 return loss
         alg_bytes = B * 2 * T * V * (2 if args.dtype == "bf16" else 4)
 
-    # The reduced scalar is read one step later (a training loop logs it), so the all-reduce of step i is issued
+    # The reduced scalars are read one step later (a training loop logs them), so the all-reduce of step i is issued
     # asynchronously and runs on RCCL's stream beside the kernel of step i+1; every collective still completes inside the
-    # timed region.
+    # timed region (tf_seq2seq_losses_amd/dist.py: pipelined_steps, covered at world size 2 by tests/test_dist_gloo.py).
+    from tf_seq2seq_losses_amd import dist as cdist
+
     def full_step():
-        loss = step()
-        s = loss.sum()  # the scalar a training loop takes from the loss (README.md:62); all-reduced when N > 1
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(s)  # the one collective of the path: scalar sum of the losses over RCCL/xGMI
-        return s
+        return cdist.all_reduce_pair(step(), async_op=False)[0]
 
     for _ in range(args.warmup):
         full_step()
@@ -322,23 +319,20 @@ def main():
     # (every 4th launch carries the pair, so that event recording does not perturb the step time it is part of)
     KEV = 4
     kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((args.steps + KEV - 1) // KEV)]
-    t0 = time.perf_counter()
-    ev0.record()
-    pending = None
-    for i in range(args.steps):
+    def timed_step():
+        i = timed_step.i
         if i % KEV == 0:
             kev[i // KEV][0].record()
         loss_t = step()
         if i % KEV == 0:
             kev[i // KEV][1].record()
-        s_t = loss_t.sum()  # the scalar a training loop takes from the loss (README.md:62); all-reduced when N > 1
-        if world > 1:
-            work = dist.all_reduce(s_t, async_op=True)  # the one collective of the path: 4 bytes over RCCL/xGMI
-            if pending is not None:
-                pending.wait()  # step i-1's sum: its all-reduce ran beside this step's kernel
-            pending = work
-    if pending is not None:
-        pending.wait()
+        timed_step.i += 1
+        return loss_t
+    timed_step.i = 0
+    t0 = time.perf_counter()
+    ev0.record()
+    # one ctc_amd_reduce_loss launch + (N > 1) one asynchronous all-reduce of [sum(loss), #finite] per step
+    cdist.pipelined_steps(timed_step, args.steps)
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:

@@ -92,6 +92,13 @@ const char *ctc_amd_pipeline_name(int kind, int wrt, int B, int T, int V, int U,
 int ctc_amd_debug_override(const char *key /*host*/, const char *value /*host*/);
 
 /*
+ * out2[0] = sum of the finite entries of loss[B], out2[1] = their number (as float): the two scalars a data-parallel
+ * training loop all-reduces (tf.reduce_sum / reduce_mean of the loss: README.md:62, tests/benchmark.py:199), in one launch.
+ * Asynchronous on `stream` like the compute entry points.
+ */
+int ctc_amd_reduce_loss(const float *loss, int B, float *out2, void *stream);
+
+/*
  * Opt-in validation of the labels (the ONLY entry point that synchronises the stream and allocates -- a few bytes from the
  * stream-ordered pool; keep it off the hot path).  Returns CTC_AMD_ELABEL if any label inside label_length (and inside
  * U / label_stride) lies outside [0, V) or equals blank_index.  Without this check such a label is not an error in the

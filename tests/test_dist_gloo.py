@@ -50,3 +50,40 @@ def test_two_rank_sharding_and_scalar_allreduce():
     assert np.array_equal(np.isfinite(got), fin) and np.abs(got[fin] - full[fin]).max() < 1e-4
     for r in range(2):
         assert abs(out[r][3] - full[fin].sum()) < 1e-3 and out[r][4] == fin.sum()
+
+
+def _loop_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tf_seq2seq_losses_amd import dist as cdist
+    calls = {"n": 0}
+
+    def step():  # CPU tensors standing in for the kernel's loss[B] of this rank and step
+        i = calls["n"]
+        calls["n"] += 1
+        loss = torch.arange(4, dtype=torch.float32) + 10.0 * i + 100.0 * rank
+        if (i + rank) % 3 == 0:
+            loss[1] = float("inf")  # an infeasible utterance: not summed, not counted
+        return loss
+    pairs = cdist.pipelined_steps(step, 7)
+    out[rank] = [p.tolist() for p in pairs]
+    dist.destroy_process_group()
+
+
+def test_pipelined_all_reduce_loop_of_the_bench():
+    """bench.py's N > 1 loop (dist.pipelined_steps): every step's [sum of finite losses, count] pair is all-reduced
+    asynchronously and waited for one step later; all seven collectives complete and carry the right numbers."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_loop_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] == out[1]
+    for i, (s, n) in enumerate(out[0]):
+        want_s, want_n = 0.0, 0
+        for rank in range(2):
+            loss = np.arange(4, dtype=np.float64) + 10.0 * i + 100.0 * rank
+            if (i + rank) % 3 == 0:
+                loss[1] = np.inf
+            want_s += loss[np.isfinite(loss)].sum()
+            want_n += int(np.isfinite(loss).sum())
+        assert abs(s - want_s) < 1e-3 and n == want_n, (i, s, n, want_s, want_n)

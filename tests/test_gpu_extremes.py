@@ -47,15 +47,23 @@ def test_tiny_vocabulary_single_frame(kind, V):
 
 @pytest.mark.parametrize("kind", ["classic", "simplified"])
 def test_long_utterances(kind):
-    """T = 5000 (five times the north-star length): 209 blocks per side in the fused kernel.  The float32 lattice carries
-    ~4e-6 of rounding per step on renormalised values of magnitude ~100 bits, which accumulates roughly linearly with T:
-    2.6e-4 at T = 1000 (tests/test_gpu_large.py), 1.3e-3 measured here -- bound 3e-3; the loss (offsets in double) keeps
-    its 1e-4 relative bound."""
+    """T = 5000 (five times the north-star length): 209 blocks per side in the fused kernel.  The linear-domain lattice
+    carries a RELATIVE rounding of 2^-24 per operation: measured max|dgrad| 3.0e-6 here (round 2) -- the 1e-4 bar holds.
+    The log-domain kernel, which redoes utterances the linear one flags, carries ~4e-6 of ABSOLUTE rounding per step on
+    renormalised logarithms of magnitude ~100: measured 1.34e-3 at this length (2.4e-4 at T = 1000), bound 2e-3; the loss
+    (offsets in double) keeps its 1e-4 relative bound on both."""
     rng = np.random.default_rng(2)
     B, T, V, U = 3, 5000, 256, 128
     logits = rng.standard_normal((B, T, V)).astype(np.float32)
     labels = rng.integers(1, V, (B, U)).astype(np.int32)
-    _check(kind, logits, labels, np.array([128, 77, 128], np.int32), np.array([5000, 4321, 2500], np.int32), tol_g=3e-3)
+    ll, tl = np.array([128, 77, 128], np.int32), np.array([5000, 4321, 2500], np.int32)
+    _check(kind, logits, labels, ll, tl)
+    from tf_seq2seq_losses_amd import _lib
+    _lib.debug_override("pipeline", "fused5")
+    try:
+        _check(kind, logits, labels, ll, tl, tol_g=2e-3)
+    finally:
+        _lib.debug_override("pipeline", "")
 
 
 @pytest.mark.parametrize("kind", ["classic", "simplified"])

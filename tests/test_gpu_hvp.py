@@ -153,8 +153,11 @@ def test_autograd_second_order_uses_hvp(kind, monkeypatch):
 @pytest.mark.parametrize("kind", ["classic", "simplified"])
 def test_hvp_north_star_size_finite_differences(kind):
     """B=4 of the north-star shape (T=1000, U=128, V=256): the dense Hessian would need 262 GB per utterance, so the
-    check is against float64 central differences of the C oracle's gradient (truncation ~1e-4 of max|Hv|; the kernel
-    measured 2.7e-4 on MI355X).  Bound: 1e-3 of max|Hv| per utterance."""
+    check is against float64 central differences of the C oracle's gradient (truncation ~1e-4 of max|Hv|).  Measured on
+    MI355X (scripts/r02_measure_tolerances.py): max|Hv - fd| / max|fd| = 2.3e-4 classic, 2.9e-4 simplified (the tangent sweep
+    is a float32 log-domain recursion over 1000 frames) -- bound 4.5e-4 = 1.5 x the measured value.  Symmetry <u,Hv> = <v,Hu>
+    on the scale |v| |Hu| of a 256k-term inner product: measured 1.3e-6 / 6.8e-7 -- bound 2e-6.  (On the scale 1 + |<v,Hu>|
+    the same differences read 1e-3..2.4e-3: 0.011 absolute on a value of 9.8 -- the inner products nearly cancel.)"""
     from tf_seq2seq_losses_amd import ops, _lib
     B, T, U, V = 4, 1000, 128, 256
     rng = np.random.default_rng(11)
@@ -166,11 +169,11 @@ def test_hvp_north_star_size_finite_differences(kind):
     assert torch.isfinite(out).all()
     outn = out.cpu().numpy().astype(np.float64)
     for b in range(B):
-        assert np.abs(outn[b] - fd[b]).max() < 1e-3 * np.abs(fd[b]).max(), b
+        assert np.abs(outn[b] - fd[b]).max() < 4.5e-4 * np.abs(fd[b]).max(), b
         assert np.all(outn[b, int(inp["logit_length"][b]):] == 0)
     # <u, Hv> = <v, Hu> at this size (256k-term inner products: compared on the scale |v| |Hu|)
     u = rng.standard_normal((B, T, V)).astype(np.float32)
     hu = ops.hvp(ops.KINDS[kind], _lib.WRT_LOGITS, _prep(inp), _t(u))[2].double()
     a, b_ = (_t(v).double() * hu).sum((1, 2)), (_t(u).double() * out.double()).sum((1, 2))
     scale = _t(v).double().flatten(1).norm(dim=1) * hu.flatten(1).norm(dim=1)
-    assert ((a - b_).abs() / scale).max().item() < 1e-4
+    assert ((a - b_).abs() / scale).max().item() < 2e-6

@@ -3,9 +3,10 @@
 configs[1]/[2]: B=256 T=1000 U=128 V=256 (loss+grad).  configs[4]: Hessian B=32 T=200 U=32 V=64 (run here at B=2:
 the samples are independent and the full-B output is 21 GB).
 At T=1000 two correct float32 log-space implementations differ by ~2e-3 in the loss and ~5e-3 in the gradient
-(SURVEY.md section 7.3); the HIP path renormalises the lattice rows every 16 frames and is compared with the float64
-C oracle (oracle/ctc_oracle.c) on the first 8 utterances: |dloss| <= 1e-4*|loss|, max|dgrad| <= 5e-4
-(measured on MI355X: ~2.6e-4 worst frame; the reference's own float32 noise at this size is ~5e-3).
+(SURVEY.md section 7.3).  The HIP path (linear-domain lattice, ctc_fused6.hip) is compared with the float64 C oracle
+(oracle/ctc_oracle.c) on the first 8 utterances at the north-star tolerance: |dloss| <= 1e-4*|loss|, max|dgrad| <= 1e-4.
+Measured on MI355X (scripts/r02_measure_tolerances.py, round 2): max|dgrad| 1.4e-6 classic / 7.3e-7 simplified, loss
+7.8e-8 relative; the log-domain kernel it replaced (ctc_fused5.hip, now the fallback): 2.2e-4 / 2.4e-4.
 """
 import numpy as np
 import pytest
@@ -47,16 +48,16 @@ def test_north_star_config_loss_and_gradient(kind, ragged):
     for b in range(0, B, 17):
         n = tl[b]
         assert np.all(gn[b, n:] == 0)                                   # padded frames: exactly zero
-        assert np.abs(gn[b, :n].sum(axis=1)).max() < 5e-4               # softmax - posterior sums to 0 per frame
+        assert np.abs(gn[b, :n].sum(axis=1)).max() < 1e-4               # softmax - posterior sums to 0 per frame (measured 2.2e-6)
         post = torch.softmax(x[b, :n].detach(), 1).cpu().numpy() - gn[b, :n]
-        assert post.min() > -5e-4 and post.max() < 1 + 5e-4             # posteriors are probabilities
+        assert post.min() > -1e-4 and post.max() < 1 + 1e-4             # posteriors are probabilities
         absent = np.setdiff1d(np.arange(1, V), labels[b, : ll[b]])
         assert np.abs(post[:, absent]).max() < 1e-6                     # tokens outside the label get no mass
     # bounded comparison with the float64 oracle
     n = 8
     rl, rg = C.loss_grad(kind, labels[:n], logits[:n], ll[:n], tl[:n], 0)
     assert (np.abs(lossn[:n] - rl) / np.abs(rl)).max() < 1e-4
-    assert np.abs(gn[:n] - rg).max() < 5e-4
+    assert np.abs(gn[:n] - rg).max() < 1e-4
     if kind == "classic":  # independent implementation: torch CPU ctc_loss, float64
         xt = torch.tensor(logits[:2], dtype=torch.float64)
         ref = torch.nn.functional.ctc_loss(torch.log_softmax(xt, 2).transpose(0, 1), torch.tensor(labels[:2].astype(np.int64)),

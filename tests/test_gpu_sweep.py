@@ -51,8 +51,8 @@ def test_shape_sweep(kind, T, U, V, B):
     if fin.any():
         assert (np.abs(lossn[fin] - rl[fin]) / np.maximum(1.0, np.abs(rl[fin]))).max() < TOL
     assert np.isfinite(gradn).all()
-    # float32 log-space arithmetic resolves ~1e-7 * |log-probability| per operation: when a sample's loss runs into the
-    # thousands of nats (sharp logits on a nearly forced alignment) posteriors carry a few 1e-4, like the T = 1000
-    # north-star case (tests/test_gpu_large.py); below that the 1e-4 bar holds
+    # The 1e-4 bar holds for every utterance the linear-domain kernel keeps.  Sharp logits (the x4 cases) on a nearly forced
+    # alignment exceed its range; they are redone in float32 LOG space, which resolves ~1e-7 * |log-probability| per
+    # operation: when the loss runs into the thousands of nats the posteriors carry a few 1e-4 (measured up to 2.4e-4)
     big = fin.any() and np.abs(rl[fin]).max() > 500
     assert np.abs(gradn - rg).max() < (5e-4 if big else TOL)

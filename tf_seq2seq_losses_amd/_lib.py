@@ -32,6 +32,7 @@ SIGNATURES = {
     "ctc_amd_last_error": (ctypes.c_char_p, []),
     "ctc_amd_pipeline_name": (ctypes.c_char_p, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "ctc_amd_debug_override": (_c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    "ctc_amd_reduce_loss": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),
     "ctc_amd_check_labels": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "ctc_amd_workspace_bytes": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_size_t)]),
     "ctc_amd_loss_grad": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),

@@ -67,6 +67,7 @@ size_t hvp_extra_bytes(int kind, int B, int T, int V, int U);
 int g_force_pipeline = 0;      // 0 = best eligible tier, 1 = v1, 2 = fused2, 5 = fused5 (log domain)
 int g_force_hessian_slab = 0;  // 1 = the general one-slab-per-wavefront Hessian kernel also for short labels
 hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec, float *out, hipStream_t st);
+hipError_t run_reduce_loss(const float *loss, int B, float *out, hipStream_t st);
 hipError_t run_check_labels(const int32_t *labels, int label_stride, const int32_t *label_length, int blank, int B, int V, int U,
                             int *bad, hipStream_t st);
 }  // namespace ctc
@@ -157,6 +158,13 @@ const char *ctc_amd_pipeline_name(int kind, int wrt, int B, int T, int V, int U,
   ctc::Layout L = ctc::make_layout(kind, B, T, U, 0);
   ctc::Problem p = make_problem(kind, wrt, nullptr, nullptr, 0, nullptr, nullptr, 0, B, T, V, U);
   return select_pipeline(p, L, want_grad != 0);
+}
+
+int ctc_amd_reduce_loss(const float *loss, int B, float *out2, void *stream) {
+  if (B < 0 || !out2 || (B > 0 && !loss)) return fail(CTC_AMD_EINVAL, "bad arguments");
+  hipError_t e = ctc::run_reduce_loss(loss, B, out2, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail(e, "reduce launch");
+  return CTC_AMD_OK;
 }
 
 int ctc_amd_check_labels(const int32_t *labels, int label_stride, const int32_t *label_length, int blank_index, int B, int V,

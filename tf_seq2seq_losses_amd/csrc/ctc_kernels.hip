@@ -683,4 +683,24 @@ hipError_t run_check_labels(const int32_t *labels, int label_stride, const int32
   return hipGetLastError();
 }
 
+// out[0] = sum of the finite losses, out[1] = their number: what a training loop all-reduces (dist.py), in ONE launch
+static __global__ __launch_bounds__(256) void reduce_loss_kernel(const float *__restrict__ loss, int B, float *__restrict__ out) {
+  __shared__ float ss[4], sn[4];
+  float s = 0.f, n = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float v = loss[b];
+    const bool fin = (v - v) == 0.f;  // false for +-inf and NaN
+    s += fin ? v : 0.f;
+    n += fin ? 1.f : 0.f;
+  }
+  s = wave_sum(s); n = wave_sum(n);
+  if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = s; sn[threadIdx.x >> 6] = n; }
+  __syncthreads();
+  if (threadIdx.x == 0) { out[0] = (ss[0] + ss[1]) + (ss[2] + ss[3]); out[1] = (sn[0] + sn[1]) + (sn[2] + sn[3]); }
+}
+hipError_t run_reduce_loss(const float *loss, int B, float *out, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, st, loss, B, out);
+  return hipGetLastError();
+}
+
 }  // namespace ctc

@@ -24,14 +24,51 @@ def shard_bounds(batch: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def reduce_loss_sum(local_loss: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """All-reduces (sum of finite losses, number of finite losses) over the ranks: ONE collective of two floats.
-    Returns (global_sum, global_count)."""
-    finite = torch.isfinite(local_loss)
-    buf = torch.stack([torch.where(finite, local_loss, torch.zeros_like(local_loss)).sum(),
-                       finite.sum().to(local_loss.dtype)])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    """All-reduces (sum of finite losses, number of finite losses) over the ranks: ONE kernel launch (ctc_amd_reduce_loss)
+    and ONE collective of two floats.  Returns (global_sum, global_count).  `async_op=True` in all_reduce_pair below gives
+    the handle instead, for loops that read the scalar a step later (bench.py)."""
+    buf, work = all_reduce_pair(local_loss, group=group, async_op=False)
     return buf[0], buf[1]
+
+
+def local_pair(local_loss: torch.Tensor) -> torch.Tensor:
+    """[sum of finite losses, number of finite losses] of this rank, float32[2] on the loss's device."""
+    if local_loss.is_cuda:
+        from . import _lib
+        buf = torch.empty(2, dtype=torch.float32, device=local_loss.device)
+        x = local_loss if (local_loss.dtype == torch.float32 and local_loss.is_contiguous()) else local_loss.float().contiguous()
+        _lib.check(_lib.load().ctc_amd_reduce_loss(x.data_ptr() if x.numel() else None, x.numel(), buf.data_ptr(),
+                                                   torch.cuda.current_stream(x.device).cuda_stream), "ctc_amd_reduce_loss")
+        return buf
+    finite = torch.isfinite(local_loss)  # CPU tensors (gloo tests): plain torch
+    return torch.stack([torch.where(finite, local_loss, torch.zeros_like(local_loss)).sum(), finite.sum().to(local_loss.dtype)]).float()
+
+
+def all_reduce_pair(local_loss: torch.Tensor, group=None, async_op: bool = False):
+    """(buffer, work): the [sum, count] pair of this rank, all-reduced in place over the group (work is None when there is
+    nothing to wait for)."""
+    buf = local_pair(local_loss)
+    work = None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return buf, (work if async_op else None)
+
+
+def pipelined_steps(step: Callable[[], torch.Tensor], steps: int, group=None):
+    """The data-parallel loop of bench.py: every step computes this rank's losses and issues the all-reduce of its
+    [sum, count] pair asynchronously; the pair of step i-1 is waited for after step i has been launched, so the
+    collective (two floats, latency-bound) runs beside the next kernel.  Returns the list of reduced pairs, all
+    complete on return."""
+    out, pending = [], None
+    for _ in range(steps):
+        buf, work = all_reduce_pair(step(), group=group, async_op=True)
+        if pending is not None and pending[1] is not None:
+            pending[1].wait()
+        pending = (buf, work)
+        out.append(buf)
+    if pending is not None and pending[1] is not None:
+        pending[1].wait()
+    return out
 
 
 def sharded_loss(loss_fn: Callable[..., torch.Tensor], labels, logits, label_length, logit_length, blank_index=0,
