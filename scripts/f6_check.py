@@ -122,6 +122,12 @@ if __name__ == "__main__":
     if which == "seeds":
         for sd in range(int(os.environ.get("F6_NSEEDS", "8"))):
             run("classic", 256, 1000, 128, 256, seed=sd, ncheck=2, reps=10)
+    if which == "stride":
+        # same work (logit_length = 1000) with different allocation strides between utterances: T_alloc rows of 1 KB each
+        for Talloc in (1000, 1001, 1003, 1008, 1024):
+            def tw(logits, labels, ll, tl):
+                tl[:] = 1000
+            run("classic", 256, Talloc, 128, 256, seed=2, ncheck=1, reps=50, tweak=tw)
     if which == "b128":
         run("classic", 128, 1000, 128, 256, seed=2, ncheck=2, reps=50)
         run("classic", 192, 1000, 128, 256, seed=2, ncheck=2, reps=50)

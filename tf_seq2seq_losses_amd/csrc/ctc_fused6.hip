@@ -567,6 +567,9 @@ struct Rows {
 #ifndef CTC_F6_PFD
 #define CTC_F6_PFD 2
 #endif
+#ifndef CTC_F6_ONLY  // experiment: which roles work in phase 2 (1 main, 2 recompute, 4 helper E stage, 8 helper G stage) and in phase 1 (16 main, 32 E stage); others only keep the barriers
+#define CTC_F6_ONLY 63
+#endif
 #ifndef CTC_F6_X
 #define CTC_F6_X 2
 #endif
@@ -650,7 +653,7 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL, VPL, XT> &S, Lds<KI
     constexpr int r = decltype(R)::value;  // = it mod PFD
     constexpr bool FAST = decltype(FASTt)::value;
     const int j = it;
-    if (FAST || (NQ > 0 && j < nb)) {
+    if ((CTC_F6_ONLY & 32) && (FAST || (NQ > 0 && j < nb))) {
       const int g = geo.absblock(1, SIDE, j);
       const int nv = FAST ? BLK : geo.nvof(g);
       float(*E)[LD::ES] = lds.E[SIDE][j % 3];
@@ -775,7 +778,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
     const int nb = geo.nblocks(1, DIR);
     for (int it = 0; it <= geo.NB; ++it) {
       const int j = it - 1;
-      if (j >= 0 && j < nb) {
+      if ((CTC_F6_ONLY & 16) && j >= 0 && j < nb) {
         const int g = geo.absblock(1, DIR, j);
         const int nv = geo.nvof(g);
         const float(*E)[LD::ES] = lds.E[DIR][j % 3];
@@ -876,7 +879,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
     int kflag = 0;
     for (int it = 0; it <= geo.NB + 2; ++it) {
       const int j = it - 2;
-      if (j >= 0 && j < nb) {
+      if ((CTC_F6_ONLY & 1) && j >= 0 && j < nb) {
         const int g = geo.absblock(2, DIR, j);
         const int nv = geo.nvof(g);
         const float(*E)[LD::ES] = lds.E[DIR][j % 3];
@@ -895,7 +898,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
         // S row entry per lane (in place of the R row, a region of 2 NL floats):
         //   NL >= 2: [aligned blank part (raw), token parts[NL] (raw; simplified: the shifted slot scaled), shifted blank part (scaled)]
         //   NL = 1 : [token part, shifted blank part]
-        // row tail .x (where the R row had cx): posterior of the boundary state, scaled (uniform).
+        // lane 0's shifted blank part also carries the posterior of the boundary state (scaled with its own K0).
         float(*KLr)[64] = lds.kl[DIR][j % 3];
         int q = -1, kR = DEAD, ks = DEAD, k0r = DEAD;
         float KL = 0.f, KS = 0.f, K0 = 0.f;
@@ -961,7 +964,11 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
             tok[0] *= KS;
             p0 = S.cx * e.bl * r0;
           }
-          const float q0 = p0 * K0;  // the boundary state (uniform)
+#ifdef CTC_F6_NOPROD  // experiment: the main chain computes no posterior parts -- results are wrong
+          qal = 0.f; qsh = 0.f; p0 = 0.f;
+          for (int jj = 0; jj < NL; ++jj) tok[jj] = 0.f;
+#endif
+          qsh = (lane == 0) ? qsh + p0 * K0 : qsh;  // the boundary state (uniform) rides in lane 0's scaled part
           float *srow = RR[d] + 2 * lane * NL;
           if constexpr (NL == 1) *reinterpret_cast<float2 *>(srow) = make_float2(tok[0], qsh);
           else if constexpr (NL == 2) *reinterpret_cast<float4 *>(srow) = make_float4(qal, tok[0], tok[1], qsh);
@@ -970,8 +977,6 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
             *reinterpret_cast<float2 *>(srow + 4) = make_float2(tok[3], qsh);
           }
           KLr[d][lane] = KL;
-          float *tq = (lane == 0) ? RR[d] + 2 * LD::UP : dump + lane;  // lanes > 0 write a sink
-          *tq = q0;
           if constexpr (!(KIND == 0 && DIR == 0)) S.step(e);
           if (ren) { S.template renorm<LV>(); setK(); }
         };
@@ -1067,7 +1072,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
   load_ck<KIND, NL>(ck_next, ck_rows, ck_k, ck_slot(0), SRS, UP, lane);
   for (int it = 0; it <= geo.NB + 2; ++it) {
     const int j = it - 1;
-    if (j >= 0 && j < nb) {
+    if ((CTC_F6_ONLY & 2) && j >= 0 && j < nb) {
       const int g = geo.absblock(2, SIDE, j);
       const int nv = geo.nvof(g);
       const float(*E)[LD::ES] = lds.E[SIDE][j % 3];
@@ -1087,7 +1092,11 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
         read_E<NL, LD>(E[d], lane, e);
         S.step(e);
       };
+#ifdef CTC_F6_NOREC  // experiment: the recompute chain does not advance -- results are wrong
+      auto stpb = [&](auto D) __attribute__((always_inline)) { (void)eb; };
+#else
       auto stpb = [&](auto D) __attribute__((always_inline)) { S.step(eb[decltype(D)::value]); };
+#endif
       auto after = [&](bool more) __attribute__((always_inline)) {
         ++s;
         if (s % RN == 0 && more) {
@@ -1240,12 +1249,16 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
       // ---- E stage (block it) ----
       const int j = it;
       SG[r] = st_cur;
-      if (FAST || j < nb) {
+      if ((CTC_F6_ONLY & 4) && (FAST || j < nb)) {
         const int g = geo.absblock(2, DIR, j);
         const int nv = FAST ? BLK : geo.nvof(g);
         float(*E)[LD::ES] = lds.E[DIR][j % 3];
         st_next = stats[fr(2, j + 1, lane)];
+#ifdef CTC_F6_NOE2  // experiment: no E stage in phase 2 (stale emission rows) -- results are wrong
+        if (false) {
+#else
         if (FAST || __builtin_expect(nv == BLK, 1)) {
+#endif
           static_for<0, FPH>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             const int d = h + NH * q;
@@ -1277,7 +1290,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
       }
       // ---- G stage (block it-3): posterior scatter + gradient rows ----
       const int gj = it - 3;
-      if (FAST || (gj >= 0 && gj < nb)) {
+      if ((CTC_F6_ONLY & 8) && (FAST || (gj >= 0 && gj < nb))) {
         const int g = geo.absblock(2, DIR, gj);
         const int nv = FAST ? BLK : geo.nvof(g);
         const float(*SR)[LD::RS] = lds.R[DIR][gj % 3];
@@ -1286,7 +1299,6 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         auto read_S = [&](int d, float &qb, float (&qt)[NL]) __attribute__((always_inline)) {
           const float *srow = SR[d] + 2 * lane * NL;
           const float kl = KLr[d][lane];
-          const float q0 = SR[d][2 * LD::UP];  // same address in every lane: LDS broadcast
           constexpr int JS = (KIND == 1) ? (DIR == 0 ? NL - 1 : 0) : -1;  // simplified: the slot whose token part is already scaled
           float qal = 0.f, qsh;
           if constexpr (NL == 1) { const float2 t = *reinterpret_cast<const float2 *>(srow); qt[0] = t.x; qsh = t.y; }
@@ -1298,7 +1310,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
           }
 #pragma unroll
           for (int jj = 0; jj < NL; ++jj) if (jj != JS) qt[jj] *= kl;
-          qb = qal * kl + qsh + ((lane == 0) ? q0 : 0.f);
+          qb = qal * kl + qsh;
         };
         if (FAST || __builtin_expect(nv == BLK, 1)) {
           // qb[FPH]: total posterior mass of this helper's first frame of the block (D6).  Mass lost by a chain is missing
