@@ -78,6 +78,26 @@ def _flags(ws, kind, B, T, V, U):
     return ws[o:o + 4 * B].view(torch.int32).cpu().numpy()
 
 
+@pytest.mark.parametrize("T,U,V", [(300, 100, 1024), (300, 60, 512), (200, 20, 700), (400, 200, 256), (330, 30, 64)])
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_benign_shapes_of_every_vocabulary_tier_stay_on_the_linear_kernel(kind, T, U, V):
+    """N(0,1) logits, utterances long enough to reach the steady-state loops of every row-segment count (V <= 256, 512, 1024;
+    the widest reloads its rows in the gradient stage): nothing is flagged, so the answer below is the linear kernel's own
+    -- a steady state entered one block early once sent every V = 1024 utterance to the log-domain fallback unnoticed."""
+    from tf_seq2seq_losses_amd import ops, _lib
+    k = ops.KINDS[kind]
+    B = 8
+    logits, labels, ll, tl = _case(B, T, U, V, seed=3, ragged=False)
+    p = ops.Prepared(_t(labels), _t(logits), _t(ll), _t(tl), 0, U=U)
+    assert _lib.pipeline_name(k, 0, B, T, V, U, True) == "fused6"
+    ws = torch.zeros(_lib.workspace_bytes(_lib.WS_LOSS_GRAD, k, B, T, V, U), dtype=torch.uint8, device=_dev())
+    loss, grad = ops.loss_grad(k, _lib.WRT_LOGITS, p, True, workspace=ws)
+    assert not _flags(ws, k, B, T, V, U).any()
+    rl, rg = C.loss_grad(kind, labels[:3], logits[:3], ll[:3], tl[:3], 0)
+    assert np.abs(grad[:3].cpu().numpy() - rg).max() < 1e-5
+    assert (np.abs(loss[:3].cpu().numpy() - rl) / rl).max() < 1e-6
+
+
 @pytest.mark.parametrize("kind", ["classic", "simplified"])
 def test_linear_kernel_flags_what_it_cannot_hold_and_nothing_else(kind):
     """Benign logits (N(0,1), the benchmark distribution): no utterance is flagged and the gradient is the float64 one to

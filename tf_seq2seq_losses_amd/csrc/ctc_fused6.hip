@@ -39,6 +39,7 @@
 // References: classic_ctc_loss.py:310-462,565-669, simplified_ctc_loss.py:291-438,456-534, base_loss.py:262-298,328-344,
 // 420-468, tools.py:27-40.
 #include "ctc_fused_common.h"
+#include "ctc_swap_reduce.h"
 
 #ifndef CTC_FUSED_KIND
 #error "compile with -DCTC_FUSED_KIND=0 (classic) or 1 (simplified)"
@@ -512,12 +513,17 @@ struct Rows {
 #pragma unroll
       for (int q = 1; q < VPL; ++q) m[f] = fmaxf(m[f], fmaxf(fmaxf(xr[f][q].x, xr[f][q].y), fmaxf(xr[f][q].z, xr[f][q].w)));
     }
-    dpp_max_n<Q>(m);
+    constexpr bool SWAP = (Q == 2 || Q == 4);  // (ctc_swap_reduce.h: all Q values through one register)
+    float mall = 0.f;
+    if constexpr (SWAP) mall = swap_reduce<Q, true>(m);
+    else dpp_max_n<Q>(m);
     float4 ev[Q][VPL];
     float sm[Q];
 #pragma unroll
     for (int f = 0; f < Q; ++f) {
-      float mx = readlane_f(m[f], 63);
+      float mx;
+      if constexpr (SWAP) mx = readlane_f(mall, SwapLanes<SWAP ? Q : 2>::lane(f));
+      else mx = readlane_f(m[f], 63);
       mx = (mx == -INFINITY) ? 0.f : mx;
       mxl[f] = mx * LOG2E;
       expo(xr[f], mxl[f], ev[f]);
@@ -525,10 +531,14 @@ struct Rows {
 #pragma unroll
       for (int q = 0; q < VPL; ++q) sm[f] += (ev[f][q].x + ev[f][q].y) + (ev[f][q].z + ev[f][q].w);
     }
-    dpp_sum_n<Q>(sm);
+    float sall = 0.f;
+    if constexpr (SWAP) sall = swap_reduce<Q, false>(sm);
+    else dpp_sum_n<Q>(sm);
 #pragma unroll
     for (int f = 0; f < Q; ++f) {
-      const float s = readlane_f(sm[f], 63);
+      float s;
+      if constexpr (SWAP) s = readlane_f(sall, SwapLanes<SWAP ? Q : 2>::lane(f));
+      else s = readlane_f(sm[f], 63);
       l2s[f] = flog2(s);
       inv[f] = __builtin_amdgcn_rcpf(s);
     }
@@ -697,7 +707,11 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL, VPL, XT> &S, Lds<KI
       }
       static_for<0, NQA>([&](auto Q) {
         constexpr int q = decltype(Q)::value;
+#ifdef CTC_F6_NT1
+        S.io.load_x_last(xb[r][q], fr(j + PFD, P0 + q));
+#else
         S.io.load_x(xb[r][q], fr(j + PFD, P0 + q));
+#endif
       });
       const bool mine = lane >= P0 && lane < P0 + NQ && lane < nv;
       float2 *dst = mine ? stats + geo.frame(SIDE, g, mine ? lane : 0) : sink;  // unconditional store: no branch
@@ -1254,6 +1268,11 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         const int nv = FAST ? BLK : geo.nvof(g);
         float(*E)[LD::ES] = lds.E[DIR][j % 3];
         st_next = stats[fr(2, j + 1, lane)];
+        // rows of the next block: their register set was freed by the G stage of the previous iteration, so the loads go out
+        // first and have the whole iteration (not the part after this block's E stage) to arrive
+#ifndef CTC_F6_NOLOAD2  // (experiment: no second read of the logits -- results are wrong)
+        static_for<0, FPH>([&](auto Q) { S.io.load_x(X[rn][decltype(Q)::value], fr(2, j + 1, h + NH * decltype(Q)::value)); });
+#endif
 #ifdef CTC_F6_NOE2  // experiment: no E stage in phase 2 (stale emission rows) -- results are wrong
         if (false) {
 #else
@@ -1283,9 +1302,6 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
             write_E(E[d], e);
           }
         }
-#ifndef CTC_F6_NOLOAD2  // (experiment: no second read of the logits -- results are wrong)
-        static_for<0, FPH>([&](auto Q) { S.io.load_x(X[rn][decltype(Q)::value], fr(2, j + 1, h + NH * decltype(Q)::value)); });
-#endif
         st_cur = st_next;
       }
       // ---- G stage (block it-3): posterior scatter + gradient rows ----
@@ -1330,12 +1346,13 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
             dbg[lane] = __float_as_int(qb[0]); dbg[64 + lane] = __float_as_int(qt[0][0]); dbg[128 + lane] = __float_as_int(qt[0][NL - 1]);
           }
 #endif
-          dpp_sum_n<FPH + 1>(qb);  // blank posteriors of the FPH frames and one total mass, one batched wave reduction
-          massbad |= !(fabsf(readlane_f(qb[FPH], 63) - 1073741824.0f) < 1073741824.0f * 1e-4f);
+          static_assert(FPH == 3, "one four-value reduction");
+          const float qall = swap_reduce<FPH + 1, false>(qb);  // blank posteriors of the FPH frames and one total mass
+          massbad |= !(fabsf(readlane_f(qall, SwapLanes<4>::lane(FPH)) - 1073741824.0f) < 1073741824.0f * 1e-4f);
           static_for<0, FPH>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             const int d = h + NH * q;
-            const float qbs = readlane_f(qb[q], 63);
+            const float qbs = readlane_f(qall, SwapLanes<4>::lane(q));
             if constexpr (RELOAD) {
               float4 ev[VPL];
               S.expo(XG[q], readlane_f(sgl.x, d), ev);
@@ -1366,10 +1383,14 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
     // full blocks of this side: all of them, except that side A ends with the utterance's last block, which may be partial
     const int nbf = nb - ((DIR == 0 && nb > 0 && geo.nvof(geo.absblock(2, DIR, nb - 1)) != BLK) ? 1 : 0);
     int it0 = 0;
-    static_for<0, RING>([&](auto R) {  // iterations 0 .. RING-1: the pipeline fills (general body)
-      if (decltype(R)::value <= geo.NB + 2) body(R, std::false_type{}, decltype(R)::value);
+    // the pipeline fills through the general body; the steady state needs a G stage on a real block (it >= 3) and starts on
+    // a multiple of RING (the register sets are addressed by it mod RING at compile time)
+    constexpr int START = ((3 + RING - 1) / RING) * RING;
+    static_for<0, START>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if (i <= geo.NB + 2) body(std::integral_constant<int, i % RING>{}, std::false_type{}, i);
     });
-    it0 = RING;
+    it0 = START;
     if (it0 + RING <= nbf) {  // steady state: iterations 3 <= it < nbf (one trip peeled, see estage1)
       static_for<0, RING>([&](auto R) { body(R, std::true_type{}, it0 + decltype(R)::value); });
       it0 += RING;
