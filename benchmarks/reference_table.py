@@ -49,8 +49,48 @@ def timeit(fn, steps, warmup):
     return float(np.mean(ts)), float(np.std(ts))
 
 
+def tsweep(a, dev):
+    """Length sweep: the reference's ragged distribution at B = 256 for growing T, labels growing
+    with T (README.md:38-43 "gradient complexity O(l^2)": frames x label positions) and labels fixed at U = 128 (then the
+    lattice is linear in T).  Forward + gradient through the public functions; ms per call and ns per lattice cell."""
+    from tf_seq2seq_losses_amd import _lib, ops
+    rows = []
+    for V in (32, 256):
+        for mode in ("labels ~ T", "labels <= 128"):
+            for T in (64, 128, 255, 500, 1000, 2000, 4000):
+                rng = np.random.default_rng(T + V)
+                tl_np = rng.integers(T // 2, T, a.B, dtype=np.int32)
+                hi = min(T // 2, 1000) if mode == "labels ~ T" else min(T // 2, 128)
+                ll_np = rng.integers(max(hi // 2, 1), max(hi, 2), a.B, dtype=np.int32)
+                U = int(ll_np.max())
+                logits = torch.from_numpy(rng.standard_normal((a.B, T, V), dtype=np.float32)).to(dev)
+                labels = torch.from_numpy(rng.integers(1, V, (a.B, U), dtype=np.int32)).to(dev)
+                ll, tl = torch.from_numpy(ll_np).to(dev), torch.from_numpy(tl_np).to(dev)
+                for name, fn, kind in (("classic_ctc_loss", ctc.classic_ctc_loss, 0), ("simple_ctc_loss", ctc.simple_ctc_loss, 1)):
+                    def gradient():
+                        x = logits.detach().requires_grad_(True)
+                        loss = fn(labels, x, ll, tl, 0)
+                        return torch.autograd.grad(torch.where(torch.isfinite(loss), loss, 0.0).sum(), x)[0]
+                    ms, sd = timeit(gradient, a.steps, a.warmup)
+                    cells = float((tl_np.astype(np.int64) * (2 * ll_np.astype(np.int64) + 1)).sum())
+                    rows.append({"V": V, "labels": mode, "T": T, "U": U, "name": name, "ms": ms, "std": sd,
+                                 "pipeline": _lib.pipeline_name(kind, 0, a.B, T, V, U, True),
+                                 "ns_per_cell": ms * 1e6 / cells, "ns_per_frame": ms * 1e6 / float(tl_np.sum())})
+                del logits
+    print(f"B={a.B}, ragged lengths (logit_length ~ U[T/2, T), label_length ~ U[hi/2, hi)), {a.steps} steps after {a.warmup} warm-up, "
+          f"forward + gradient, wall clock per call incl. Python, {torch.cuda.get_device_name(0)}")
+    print("| V | labels | T | max label | function | pipeline | ms | ns per frame | ns per lattice cell |")
+    print("|--:|:--|--:|--:|:--|:--|--:|--:|--:|")
+    for r in rows:
+        print(f"| {r['V']} | {r['labels']} | {r['T']} | {r['U']} | `{r['name']}` | {r['pipeline']} | {r['ms']:.3f} | {r['ns_per_frame']:.2f} | {r['ns_per_cell']:.4f} |")
+    if a.json:
+        with open(a.json, "w") as fh:
+            json.dump({"config": vars(a), "device": torch.cuda.get_device_name(0), "rows": rows}, fh, indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--tsweep", action="store_true", help="length sweep instead of the README table")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--B", type=int, default=256)
@@ -59,6 +99,8 @@ def main():
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    if a.tsweep:
+        return tsweep(a, dev)
     labels, logits, ll, tl = make_inputs(a.B, a.T, a.V, 0, dev)
     v = torch.randn_like(logits)
     impls = {"torch.nn.functional.ctc_loss": torch_ctc, "classic_ctc_loss": ctc.classic_ctc_loss,

@@ -221,3 +221,26 @@ def test_unaligned_base_pointers(kind, dtype, off):
     else:
         assert ((gv.float() - g0.float()).abs() <= 2.0 ** -7 * g0.float().abs() + 1e-6).all()  # both rounded to bfloat16: one ulp apart at most
     assert (gw[:, :, :off] == 777.0).all() and (gw[:, :, off + V:] == 777.0).all()
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_wide_vocabulary_blank_in_a_later_pass(kind):
+    """V = 2560 (three 1024-column passes, the last one half full) with the blank at index 1500: its posterior lands in
+    the second pass, label tokens in all three; repeated tokens share a bin."""
+    from tf_seq2seq_losses_amd import ops, _lib
+    B, T, U, V, blank = 3, 30, 11, 2560, 1500
+    rng = np.random.default_rng(11)
+    logits = rng.standard_normal((B, T, V)).astype(np.float32)
+    labels = rng.integers(0, V - 1, (B, U)).astype(np.int32)
+    labels[labels >= blank] += 1          # any token but the blank
+    labels[0, 3:7] = labels[0, 3]         # a run of repeats
+    labels[1, ::2] = 2559                 # the last column, many times
+    ll = np.array([U, U - 2, 5], np.int32)
+    tl = np.array([T, T - 4, T], np.int32)
+    p = ops.Prepared(_t(labels), _t(logits), _t(ll), _t(tl), blank, U=U)
+    assert _lib.pipeline_name(ops.KINDS[kind], 0, B, T, V, U, True) == "v1"
+    loss, grad = ops.loss_grad(ops.KINDS[kind], _lib.WRT_LOGITS, p, True)
+    rl, rg = C.loss_grad(kind, labels, logits, ll, tl, blank)
+    assert (np.abs(loss.cpu().numpy() - rl) / np.abs(rl)).max() < 1e-5
+    assert np.abs(grad.cpu().numpy() - rg).max() < TOL
+    assert not grad[1, T - 4:].any()

@@ -12,6 +12,7 @@
 //                 softmax - posterior write (classic_ctc_loss.py:565-669, simplified_ctc_loss.py:456-534,
 //                 base_loss.py:262-298, 420-468 and TF's autodiff of tools.py:37-39).
 #include "ctc_common.h"
+#include "ctc_amd.h"
 
 namespace ctc {
 
@@ -40,17 +41,32 @@ __global__ __launch_bounds__(256) void emit_kernel(Problem p, Layout L, float *_
   float mx = -INFINITY, sum = 0.f, log2sum = 0.f;
   if (p.wrt == 0) {
     if (!bf && ((V | xoff) & 3) == 0 && (p.align_bits & 15) == 0) {
-      for (int k = lane * 4; k < V; k += 256) {
-        float4 v = *reinterpret_cast<const float4 *>(x + k);
-        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+      // ONE pass over the row, eight 16-byte loads per lane in flight: every lane keeps a running (maximum, sum of
+      // exp(x - maximum)) of its own columns, the lanes are combined once at the end (two passes with one load in flight
+      // each read a V = 2048 row at 2.7 TB/s chip-wide)
+      float m = -INFINITY, s = 0.f;
+      for (int k0 = lane * 4; k0 < V; k0 += 256 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = k0 + 256 * q;
+          v[q] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+          if (k < V) v[q] = *reinterpret_cast<const float4 *>(x + k);
+        }
+        float cm = m;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cm = fmaxf(fmaxf(cm, fmaxf(v[q].x, v[q].y)), fmaxf(v[q].z, v[q].w));
+        const float mr = (cm == -INFINITY) ? 0.f : cm;
+        s *= fexp2((m - mr) * LOG2E);  // (m = -inf: s is 0 and stays 0)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          s += (fexp2((v[q].x - mr) * LOG2E) + fexp2((v[q].y - mr) * LOG2E)) + (fexp2((v[q].z - mr) * LOG2E) + fexp2((v[q].w - mr) * LOG2E));
+        m = cm;
       }
-      mx = wave_max(mx);
+      mx = wave_max(m);
       const float mref = (mx == -INFINITY) ? 0.f : mx;
-      for (int k = lane * 4; k < V; k += 256) {
-        float4 v = *reinterpret_cast<const float4 *>(x + k);
-        sum += fexp2((v.x - mref) * LOG2E) + fexp2((v.y - mref) * LOG2E) + fexp2((v.z - mref) * LOG2E) +
-               fexp2((v.w - mref) * LOG2E);
-      }
+      sum = s * fexp2((m - mref) * LOG2E);
+      if (!(m > -INFINITY)) sum = 0.f;  // a lane whose columns are all -inf (or that holds none)
     } else {
       for (int k = lane; k < V; k += 64) mx = fmaxf(mx, xat(k));
       mx = wave_max(mx);
@@ -500,6 +516,116 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
   }
 }
 
+// Wide vocabularies (V > 1024, float32 rows, 16-byte aligned): the same gradient with the vocabulary walked in passes of
+// 1024 columns.  The posterior of every label position is computed ONCE into a per-wavefront table (fixed point); each
+// pass zeroes a 4 KB bin array, adds the positions whose token falls into it, and streams its 1024 columns (logits in,
+// gradient out).  LDS per wavefront is 8 KB whatever V is (grad_kernel needs 4 V bytes: at V = 8192 that left 4
+// wavefronts per CU and 2.3 TB/s), and the bins are touched twice per column instead of four times.
+template <int KIND>
+__global__ __launch_bounds__(256) void grad_wide_kernel(Problem p, Layout L, const float *__restrict__ emis,
+                                                         const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                         const double *__restrict__ logp, const float *__restrict__ d_loss,
+                                                         float *__restrict__ grad) {
+  constexpr int CH = 1024;
+  __shared__ __attribute__((aligned(16))) unsigned bins_s[4][CH];
+  __shared__ unsigned qtab_s[4][CTC_AMD_MAX_U];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long row = (long)blockIdx.x * 4 + w;
+  if (row >= (long)p.B * p.T) return;
+  const int b = (int)(row / p.T), t = (int)(row % p.T);
+  const int V = p.V, UP = L.UP;
+  float *g = grad + (long)b * p.gsb + (long)t * p.gst;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  auto gput4 = [&](int k, float4 r) {
+    v4f v = {r.x, r.y, r.z, r.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(g + k));
+  };
+  const int len = clampi(p.logit_length[b], 0, p.T);
+  const double lp = logp[b];
+  if (t >= len || lp == -INFINITY) {  // padded frames and infeasible samples: exactly zero (base_loss.py:283-298)
+    for (int k = lane * 4; k < V; k += 256) gput4(k, make_float4(0.f, 0.f, 0.f, 0.f));
+    return;
+  }
+  const int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  unsigned *bins = bins_s[w];
+  unsigned *qtab = qtab_s[w];
+  auto tofix = [](float q) -> unsigned { return (unsigned)(fminf(q, 1.0f) * 1073741824.0f + 0.5f); };
+  const int32_t *lab = p.labels + (long)b * p.label_stride;
+  const float *ra = alpha + ((long)b * (p.T + 1) + (KIND == 0 ? t + 1 : t)) * L.SRS;
+  const float *rb = beta + ((long)b * (p.T + 1) + t + 1) * L.SRS;
+  const int offpos = (KIND == 0 ? 2 * UP : UP) + 2;
+  const double scale = (double)ra[offpos] + (double)ra[offpos + 1] + (double)rb[offpos] + (double)rb[offpos + 1] - lp;
+  auto post = [&](float a_, float b_) -> float { return fminf(fexp2((float)((double)a_ + (double)b_ + scale)), 1.0f); };
+  auto post3 = [&](float a_, float b_, float c_) -> float { return fminf(fexp2((float)((double)a_ + (double)b_ + (double)c_ + scale)), 1.0f); };
+  // posteriors of the label positions (see grad_kernel for the regrouping), once per row
+  float qblank = 0.f;
+  if constexpr (KIND == 0) {
+    for (int i = lane; i < UP; i += 64) {
+      const float2 a = *reinterpret_cast<const float2 *>(ra + 2 * i);
+      const float2 bb = *reinterpret_cast<const float2 *>(rb + 2 * i);
+      qblank += post(a.x, bb.x);
+      qtab[i] = (i < ll) ? tofix(post(a.y, bb.y)) : 0u;
+    }
+    if (lane == 0) qblank += post(ra[2 * UP], rb[2 * UP]);
+  } else {
+    const float *er = emis + row * (long)L.ERS;
+    const float bl = er[UP];
+    for (int i = lane; i < UP; i += 64) {
+      const float ai = ra[i], bi = rb[i];
+      qblank += post3(ai, bi, bl);
+      const float aprev = (i == 0) ? ra[UP] : ra[i - 1];
+      qtab[i] = (i < ll) ? tofix(post3(aprev, er[i], bi)) : 0u;
+    }
+    if (lane == 0) qblank += post3(ra[UP], rb[UP], bl);
+  }
+  const unsigned qbfix = tofix(wave_sum(qblank));
+  const float dl = d_loss ? d_loss[b] : 1.0f;
+  const float *x = p.logits + (long)b * p.xsb + (long)t * p.xst;
+  const float mx = emis[row * (long)L.ERS + UP + 1];
+  const float l2s = emis[row * (long)L.ERS + UP + 2];
+  const bool wrt_logits = p.wrt == 0;
+  for (int c0 = 0; c0 < V; c0 += CH) {
+    float4 xv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // this pass's logits first: four loads in flight under the LDS work
+      const int k = c0 + lane * 4 + 256 * q;
+      xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wrt_logits && k < V) xv[q] = *reinterpret_cast<const float4 *>(x + k);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4 *>(bins + lane * 4 + 256 * q) = make_uint4(0u, 0u, 0u, 0u);
+    __builtin_amdgcn_wave_barrier();  // (LDS operations of one wavefront execute in program order)
+    for (int i = lane; i < ll; i += 64) {
+      const int tok = (i < p.label_stride) ? lab[i] : p.blank;
+      const unsigned r = (unsigned)(tok - c0);
+      if (tok >= 0 && tok < V && tok != p.blank && r < (unsigned)CH) atomicAdd(&bins[r], qtab[i]);
+    }
+    if (lane == 0 && p.blank >= c0 && p.blank < c0 + CH && p.blank < V) bins[p.blank - c0] = qbfix;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = c0 + lane * 4 + 256 * q;
+      if (k < V) {
+        const uint4 u = *reinterpret_cast<const uint4 *>(bins + lane * 4 + 256 * q);
+        const float c = 9.31322574615478515625e-10f;
+        float4 r;
+        if (wrt_logits) {
+          // g_x[k] = d_loss * (softmax(x)[k] - post[k])  (TF autodiff of tools.py:37-39 applied to base_loss.py:150-153)
+          r.x = dl * (fexp2((xv[q].x - mx) * LOG2E - l2s) - (float)u.x * c);
+          r.y = dl * (fexp2((xv[q].y - mx) * LOG2E - l2s) - (float)u.y * c);
+          r.z = dl * (fexp2((xv[q].z - mx) * LOG2E - l2s) - (float)u.z * c);
+          r.w = dl * (fexp2((xv[q].w - mx) * LOG2E - l2s) - (float)u.w * c);
+        } else {
+          r = make_float4(-dl * ((float)u.x * c), -dl * ((float)u.y * c), -dl * ((float)u.z * c), -dl * ((float)u.w * c));  // base_loss.py:262-268
+        }
+        gput4(k, r);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // convert: workspace rows -> the reference's alpha/beta tensors (natural log, -inf, padded frames filled in)
 // ------------------------------------------------------------------------------------------------
@@ -605,6 +731,14 @@ hipError_t run_grad(const Problem &p, const Layout &L, char *ws, const float *d_
   const float *alpha = reinterpret_cast<const float *>(ws + L.off_alpha);
   const float *beta = reinterpret_cast<const float *>(ws + L.off_beta);
   const double *logp = reinterpret_cast<const double *>(ws + L.off_logp);
+  const bool wide = p.V > 1024 && p.xdtype == 0 && p.gdtype == 0 && (p.align_bits & 15) == 0 &&
+                    ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0 && L.UP <= CTC_AMD_MAX_U;
+  if (wide) {
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (p.kind == 0) hipLaunchKernelGGL(grad_wide_kernel<0>, grid, block, 0, st, p, L, emis, alpha, beta, logp, d_loss, grad);
+    else hipLaunchKernelGGL(grad_wide_kernel<1>, grid, block, 0, st, p, L, emis, alpha, beta, logp, d_loss, grad);
+    return hipGetLastError();
+  }
   int wpb = 4;
   while (wpb > 1 && (size_t)wpb * p.V * 4 > 64 * 1024) wpb >>= 1;
   const size_t shmem = (size_t)wpb * p.V * 4;
