@@ -157,6 +157,10 @@ def test_check_labels():
     assert b"2 label" in lib.ctc_amd_last_error()
     with pytest.raises(ValueError):
         _lib.check(_lib.ELABEL, "ctc_amd_check_labels")
+    import tf_seq2seq_losses_amd as ctc
+    with pytest.raises(ValueError):
+        ctc.check_labels(bad, ll, V, 0)          # the public helper: NumPy or torch labels
+    ctc.check_labels(labels, ll, V, 0)           # clean labels pass
 
 
 @pytest.mark.parametrize("kind", ["classic", "simplified"])

@@ -9,7 +9,8 @@ from .losses import (  # noqa: F401
     ClassicCtcLossData,
     SimplifiedCtcLossData,
 )
+from .ops import check_labels  # noqa: F401
 
 __version__ = "0.1.0"
 __all__ = ["classic_ctc_loss", "simplified_ctc_loss", "simple_ctc_loss", "ctc_loss", "ctc_loss_from_logproba",
-           "ClassicCtcLossData", "SimplifiedCtcLossData"]
+           "ClassicCtcLossData", "SimplifiedCtcLossData", "check_labels"]

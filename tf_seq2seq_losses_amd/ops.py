@@ -233,3 +233,23 @@ def hvp(kind: int, wrt: int, p: Prepared, vec: torch.Tensor, want_grad: bool = F
                              ws.data_ptr(), ws.numel(), _stream(p.device))
     _lib.check(rc, "ctc_amd_hvp")
     return loss, grad, out
+
+
+def check_labels(labels, label_length, num_tokens: int, blank_index: int = 0) -> None:
+    """Opt-in validation (off the hot path: synchronises): raises ValueError if a label inside its `label_length` lies
+    outside [0, num_tokens) or equals `blank_index` -- what TF-CPU's gather reports as InvalidArgumentError for
+    out-of-range labels (base_loss.py:328-344).  The loss functions themselves treat such a label as an impossible
+    emission (loss +inf, zero gradient)."""
+    labels = torch.as_tensor(labels)
+    label_length = torch.as_tensor(label_length)
+    if not labels.is_cuda:
+        labels = labels.cuda()
+    label_length = label_length.to(labels.device)
+    labels = labels.to(torch.int32).contiguous()
+    label_length = label_length.to(torch.int32).contiguous()
+    B, U = int(labels.shape[0]), int(labels.shape[1])
+    if B == 0 or U == 0:
+        return
+    with _on_device(labels.device):
+        _lib.check(_lib.load().ctc_amd_check_labels(_ptr(labels), U, _ptr(label_length), int(blank_index), B, int(num_tokens), U,
+                                                    _stream(labels.device)), "ctc_amd_check_labels")
