@@ -22,6 +22,8 @@ for U in (0, 1, 2, 63, 64, 65, 127, 128, 129, 200):
 CASES += [(300, 200, 512, 3), (420, 256, 300, 2), (64, 20, 512, 5), (13, 3, 260, 4), (600, 256, 512, 2)]
 # four row segments per lane (513 .. 1024 tokens): the G stage re-reads its logits rows
 CASES += [(150, 100, 1024, 3), (77, 30, 700, 4), (40, 128, 1021, 2), (260, 64, 516, 2)]
+# eight label positions per lane (257 .. 512): 3-frame blocks, one helper per side
+CASES += [(700, 300, 256, 2), (560, 512, 128, 2), (90, 400, 300, 3), (1040, 512, 512, 1), (13, 257, 29, 3), (333, 260, 60, 3)]
 # wide vocabularies (V > 1024: three-kernel pipeline, single-pass row statistics, gradient in 1024-column passes) incl. a
 # last pass that is not full, V not a multiple of 4 (scalar path) and the blank in a later pass
 CASES += [(40, 12, 2048, 3), (33, 30, 4096, 2), (21, 9, 8192, 2), (50, 20, 3000, 3), (30, 8, 2050, 2), (25, 70, 1028, 3)]

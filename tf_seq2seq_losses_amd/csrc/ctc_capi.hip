@@ -14,8 +14,8 @@ hipError_t run_convert(const Problem &p, const Layout &L, char *ws, float *alpha
 hipError_t run_fused_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 hipError_t run_fused_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 #define CTC_F5_DECL(name) hipError_t name(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, bool only_flagged, hipStream_t st)
-CTC_F5_DECL(run_fused5_classic_nl1); CTC_F5_DECL(run_fused5_classic_nl2); CTC_F5_DECL(run_fused5_classic_nl4);
-CTC_F5_DECL(run_fused5_simplified_nl1); CTC_F5_DECL(run_fused5_simplified_nl2); CTC_F5_DECL(run_fused5_simplified_nl4);
+CTC_F5_DECL(run_fused5_classic_nl1); CTC_F5_DECL(run_fused5_classic_nl2); CTC_F5_DECL(run_fused5_classic_nl4); CTC_F5_DECL(run_fused5_classic_nl8);
+CTC_F5_DECL(run_fused5_simplified_nl1); CTC_F5_DECL(run_fused5_simplified_nl2); CTC_F5_DECL(run_fused5_simplified_nl4); CTC_F5_DECL(run_fused5_simplified_nl8);
 #undef CTC_F5_DECL
 #define CTC_F6_DECL(name) hipError_t name(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st)
 CTC_F6_DECL(run_fused6_classic_nl1); CTC_F6_DECL(run_fused6_classic_nl2); CTC_F6_DECL(run_fused6_classic_nl4);
@@ -29,7 +29,8 @@ inline bool plain_format(const Problem &p) {  // contiguous float32 [B,T,V] logi
 inline bool fused5_eligible(const Problem &p, const Layout &L) {
   // producer formats: both tensors float32 or both bfloat16, strides keeping the 16-byte (8-byte) row accesses aligned
   // (bfloat16 needs 8-byte aligned rows: V and the strides multiples of 4; float32 takes any V <= 256 and any stride)
-  return p.wrt == 0 && (p.V <= 512 || (p.V <= 1024 && L.NL <= 2)) && L.NL <= 4 && p.B > 0 && p.T > 0 && p.xdtype == p.gdtype &&
+  // (U <= 512: eight label positions per lane, 3-frame blocks)
+  return p.wrt == 0 && (p.V <= 512 || (p.V <= 1024 && L.NL <= 2)) && L.NL <= 8 && p.B > 0 && p.T > 0 && p.xdtype == p.gdtype &&
          (p.xdtype == 0 || (((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0 && (p.align_bits & 7) == 0));
 }
 inline hipError_t run_fused5(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, bool only_flagged, hipStream_t st) {
@@ -37,10 +38,12 @@ inline hipError_t run_fused5(const Problem &p, const Layout &L, char *ws, float 
     case 1: return p.kind == 0 ? run_fused5_classic_nl1(p, L, ws, loss, d_loss, grad, only_flagged, st) : run_fused5_simplified_nl1(p, L, ws, loss, d_loss, grad, only_flagged, st);
     case 2: return p.kind == 0 ? run_fused5_classic_nl2(p, L, ws, loss, d_loss, grad, only_flagged, st) : run_fused5_simplified_nl2(p, L, ws, loss, d_loss, grad, only_flagged, st);
     case 4: return p.kind == 0 ? run_fused5_classic_nl4(p, L, ws, loss, d_loss, grad, only_flagged, st) : run_fused5_simplified_nl4(p, L, ws, loss, d_loss, grad, only_flagged, st);
+    case 8: return p.kind == 0 ? run_fused5_classic_nl8(p, L, ws, loss, d_loss, grad, only_flagged, st) : run_fused5_simplified_nl8(p, L, ws, loss, d_loss, grad, only_flagged, st);
     default: return hipErrorInvalidValue;
   }
 }
-// The linear-domain kernel (ctc_fused6.hip) covers the shapes of fused5 and is followed by a fused5 launch restricted to the
+inline bool fused6_eligible(const Problem &p, const Layout &L) { return fused5_eligible(p, L) && L.NL <= 4; }
+// The linear-domain kernel (ctc_fused6.hip) covers the shapes of fused5 up to 256 label positions and is followed by a fused5 launch restricted to the
 // utterances it flagged (dynamic range beyond float32 mantissas with per-lane exponents; normally none).
 inline hipError_t run_fused6(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
   hipError_t e;
@@ -130,8 +133,8 @@ static const char *select_pipeline(const ctc::Problem &p, const ctc::Layout &L, 
   const int forced = ctc::g_force_pipeline;
   if (forced == 1) return "v1";
   // loss only (grad == NULL): fused5 / fused6 stop at the meeting point of their two chains; fused2 needs a gradient
-  if (forced == 0 && ctc::fused5_eligible(p, L)) return "fused6";
-  if (forced == 5 && ctc::fused5_eligible(p, L)) return "fused5";
+  if (forced == 0 && ctc::fused6_eligible(p, L)) return "fused6";
+  if ((forced == 0 || forced == 5) && ctc::fused5_eligible(p, L)) return "fused5";
   if (!want_grad) return "v1";
   if (ctc::fused_eligible(p, L)) return "fused2";
   return "v1";

@@ -249,13 +249,15 @@ template <int BLK, int NH, int NL>
 struct P1Split {
   // NH = 4 (12-frame blocks): X / X / Y / Y / R as above.  NH = 2 (6-frame blocks of the 4-positions-per-lane variant):
   // the two helpers and the recompute wavefront take a third each.
-  static constexpr int X = NH == 4 ? CTC_F5_X : BLK / 3, Y = NH == 4 ? CTC_F5_Y : BLK / 3;
-  static constexpr int R = NH == 4 ? BLK - 2 * X - 2 * Y : BLK - X - Y;
-  static_assert(NH == 4 || NH == 2, "helpers per side");
+  // NH = 1 (3-frame blocks of the 8-positions-per-lane variant): two frames for the helper, one for the recompute wavefront.
+  static constexpr int X = NH == 4 ? CTC_F5_X : NH == 2 ? BLK / 3 : 2, Y = NH == 4 ? CTC_F5_Y : NH == 2 ? BLK / 3 : 0;
+  static constexpr int R = NH == 4 ? BLK - 2 * X - 2 * Y : NH == 2 ? BLK - X - Y : BLK - X;
+  static_assert(NH == 4 || NH == 2 || NH == 1, "helpers per side");
   static_assert(X >= 0 && Y >= 0 && R >= 0 && X <= 6 && Y <= 6 && R <= 6, "phase-1 split: at most 6 frames per worker");
   // worker: 0 .. NH-1 = helpers, NH = recompute wavefront
   static constexpr int count(int worker) {
     if (NH == 4) return worker < 2 ? X : worker < 4 ? Y : R;
+    if (NH == 1) return worker == 0 ? X : R;
     return worker == 0 ? X : worker == 1 ? Y : R;
   }
   static constexpr int first(int worker) {
@@ -658,9 +660,11 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         case 2: estage1<KIND, NL, NH, BLK, VPL, DIR, SP::first(2), SP::count(2)>(S, lds, geo, stats, dump, lane, st); break;
         default: estage1<KIND, NL, NH, BLK, VPL, DIR, SP::first(3), SP::count(3)>(S, lds, geo, stats, dump, lane, st); break;
       }
-    } else {
+    } else if constexpr (NH == 2) {
       if (h == 0) estage1<KIND, NL, NH, BLK, VPL, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, dump, lane, st);
       else estage1<KIND, NL, NH, BLK, VPL, DIR, SP::first(1), SP::count(1)>(S, lds, geo, stats, dump, lane, st);
+    } else {
+      estage1<KIND, NL, NH, BLK, VPL, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, dump, lane, st);
     }
   }
 
@@ -898,7 +902,11 @@ hipError_t CTC_F5_ENTRY(const Problem &p, const Layout &L, char *ws, float *loss
   // logits rows then needs the 256-register budget of the 8-wavefront configuration (6-frame blocks, two helpers a side).
   // 129 .. 256 label positions (four per lane): the LDS rows are twice as long -- the 8-wavefront configuration as well.
   // 513 .. 1024 tokens: four segments per lane; the G stage re-reads its logits rows (no room for the five-block ring).
-#if CTC_FUSED5_NL == 4
+#if CTC_FUSED5_NL == 8
+  // 257 .. 512 label positions (eight per lane): LDS rows of 4 KB leave room for 3-frame blocks, one helper a side (6 wavefronts)
+  return p.V <= 256 ? launch5<8, 1, 3, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, perm, only_if, st)
+                    : launch5<8, 1, 3, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, perm, only_if, st);
+#elif CTC_FUSED5_NL == 4
   return p.V <= 256 ? launch5<4, 2, 6, 1>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, perm, only_if, st)
                     : launch5<4, 2, 6, 2>(p, L, alpha, beta, logp, stats, loss, d_loss, grad, stamp, perm, only_if, st);
 #else

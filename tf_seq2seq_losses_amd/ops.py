@@ -9,7 +9,7 @@ import torch
 from . import _lib
 
 KINDS = {"classic": _lib.CLASSIC, "simplified": _lib.SIMPLIFIED}
-FUSED_MAX_U = 256  # label positions the fused kernels hold (four per lane); wider label tensors may still have short labels
+FUSED_MAX_U = 512  # label positions the fused kernels hold (eight per lane); wider label tensors may still have short labels
 
 
 def _require_gpu(t: torch.Tensor) -> None:
