@@ -21,7 +21,7 @@ def flags_of(ws, kind, B, T, V, U):
     o = 0
     o = al(o + B * T * ERS * 4); o = al(o + B * (T + 1) * SRS * 4); o = al(o + B * (T + 1) * SRS * 4)
     o = al(o + B * 8); o = al(o + B * 2 * 1024); o = al(o + B * 4)
-    o = al(o + B * 2 * ((T + 5) // 6 + 3) * 64 * 4)
+    o = al(o + B * 2 * ((T + 2) // 3 + 3) * 64 * 4)
     if os.environ.get("F6_STAMPS"):
         st = ws[o + 4 * B:o + 4 * B + B * 512].view(torch.int64).cpu().numpy().reshape(B, 16, 4)[:, :12]
         med = np.median(st, axis=0)
@@ -200,3 +200,9 @@ if __name__ == "__main__":
         run("classic", 256, 500, 60, 512, ncheck=4)
         run("classic", 256, 300, 100, 1024, ncheck=4)
         run("classic", 512, 1000, 128, 256, ragged=True, ncheck=4)
+    if which == "long":
+        for kind in ("classic", "simplified"):
+            for U in (257, 300, 400, 512):
+                run(kind, 256, 1000, U, 256, seed=1, ncheck=2, reps=20)
+        run("classic", 64, 2000, 512, 256, seed=1, ncheck=1, reps=5)
+        run("classic", 256, 1000, 512, 512, seed=1, ncheck=1, reps=10)

@@ -74,7 +74,7 @@ def _flags(ws, kind, B, T, V, U):
     UP = nl * 64; ERS = UP + 4; SRS = (2 * UP if kind == 0 else UP) + 8
     o = al(B * T * ERS * 4); o = al(o + B * (T + 1) * SRS * 4); o = al(o + B * (T + 1) * SRS * 4)
     o = al(o + B * 8); o = al(o + B * 2 * 1024); o = al(o + B * 4)
-    o = al(o + B * 2 * ((T + 5) // 6 + 3) * 64 * 4)
+    o = al(o + B * 2 * ((T + 2) // 3 + 3) * 64 * 4)
     return ws[o:o + 4 * B].view(torch.int32).cpu().numpy()
 
 

@@ -18,8 +18,8 @@ CTC_F5_DECL(run_fused5_classic_nl1); CTC_F5_DECL(run_fused5_classic_nl2); CTC_F5
 CTC_F5_DECL(run_fused5_simplified_nl1); CTC_F5_DECL(run_fused5_simplified_nl2); CTC_F5_DECL(run_fused5_simplified_nl4); CTC_F5_DECL(run_fused5_simplified_nl8);
 #undef CTC_F5_DECL
 #define CTC_F6_DECL(name) hipError_t name(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st)
-CTC_F6_DECL(run_fused6_classic_nl1); CTC_F6_DECL(run_fused6_classic_nl2); CTC_F6_DECL(run_fused6_classic_nl4);
-CTC_F6_DECL(run_fused6_simplified_nl1); CTC_F6_DECL(run_fused6_simplified_nl2); CTC_F6_DECL(run_fused6_simplified_nl4);
+CTC_F6_DECL(run_fused6_classic_nl1); CTC_F6_DECL(run_fused6_classic_nl2); CTC_F6_DECL(run_fused6_classic_nl4); CTC_F6_DECL(run_fused6_classic_nl8);
+CTC_F6_DECL(run_fused6_simplified_nl1); CTC_F6_DECL(run_fused6_simplified_nl2); CTC_F6_DECL(run_fused6_simplified_nl4); CTC_F6_DECL(run_fused6_simplified_nl8);
 #undef CTC_F6_DECL
 // shapes the checkpoint + recompute kernel (ctc_fused5.hip) is instantiated for: logits input, V <= 512 (smaller
 // vocabularies run with the lanes beyond V masked; V or strides not a multiple of 4: element-wise row accesses), U <= 256
@@ -42,7 +42,7 @@ inline hipError_t run_fused5(const Problem &p, const Layout &L, char *ws, float 
     default: return hipErrorInvalidValue;
   }
 }
-inline bool fused6_eligible(const Problem &p, const Layout &L) { return fused5_eligible(p, L) && L.NL <= 4; }
+inline bool fused6_eligible(const Problem &p, const Layout &L) { return fused5_eligible(p, L); }
 // The linear-domain kernel (ctc_fused6.hip) covers the shapes of fused5 up to 256 label positions and is followed by a fused5 launch restricted to the
 // utterances it flagged (dynamic range beyond float32 mantissas with per-lane exponents; normally none).
 inline hipError_t run_fused6(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
@@ -51,6 +51,7 @@ inline hipError_t run_fused6(const Problem &p, const Layout &L, char *ws, float 
     case 1: e = p.kind == 0 ? run_fused6_classic_nl1(p, L, ws, loss, d_loss, grad, st) : run_fused6_simplified_nl1(p, L, ws, loss, d_loss, grad, st); break;
     case 2: e = p.kind == 0 ? run_fused6_classic_nl2(p, L, ws, loss, d_loss, grad, st) : run_fused6_simplified_nl2(p, L, ws, loss, d_loss, grad, st); break;
     case 4: e = p.kind == 0 ? run_fused6_classic_nl4(p, L, ws, loss, d_loss, grad, st) : run_fused6_simplified_nl4(p, L, ws, loss, d_loss, grad, st); break;
+    case 8: e = p.kind == 0 ? run_fused6_classic_nl8(p, L, ws, loss, d_loss, grad, st) : run_fused6_simplified_nl8(p, L, ws, loss, d_loss, grad, st); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;

@@ -39,6 +39,15 @@ __device__ __forceinline__ float from_next_lane(float x, float fill) {
   return __int_as_float(v);
 }
 
+// Lanes of ONE wavefront exchanging data through LDS (scatter by one lane, read by another): the hardware executes the
+// LDS operations of a wavefront in program order, but the compiler reasons per thread -- without a fence it may forward a
+// lane's own earlier store to its load and skip the read (it did, for lanes that sit out a conditional atomic).
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
@@ -121,7 +130,7 @@ inline Layout make_layout(int kind, int B, int T, int U, size_t extra_bytes) {
   L.off_perm = o;  o = al(o + (size_t)B * 4);  // longest-first order of the utterances (fused kernel, B > number of CUs)
   // linear-domain fused kernel (ctc_fused6.hip): per-lane exponents of its checkpoint rows ([B][2][T/6 + 3][64] int32) and the
   // per-utterance flags that send an utterance to the log-domain kernel
-  L.off_kexp = o;  o = al(o + (size_t)B * 2 * ((T + 5) / 6 + 3) * 64 * 4);
+  L.off_kexp = o;  o = al(o + (size_t)B * 2 * ((T + 2) / 3 + 3) * 64 * 4);
   L.off_flags = o; o = al(o + (size_t)B * 4 + (size_t)B * 2048 * 4);  // (+ 8 KB per utterance for diagnostic builds)
   L.off_meet = o;  o = al(o + (size_t)B * 8);  // per utterance: posterior scale (integer exponent, mantissa factor) from the meeting point
   L.off_extra = o; o = al(o + extra_bytes);

@@ -550,10 +550,16 @@ struct Rows {
   // posterior of slot j, both in units of 2^-30; ev = exp(x - rowmax) of this lane's elements, inv = 1 / sum exp
   __device__ __forceinline__ void grad_row(int t, float qb, const float (&qt)[NL], const float4 (&ev)[VPL], float inv) const {
 #pragma unroll
-    for (int q = 0; q < VPL; ++q) *reinterpret_cast<float4 *>(bins + 256 * q + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < VPL; ++q) *reinterpret_cast<uint4 *>(bins + 256 * q + lane * 4) = make_uint4(0u, 0u, 0u, 0u);  // (same type as the atomics and the read: float stores may be reordered against them)
     char *bb = reinterpret_cast<char *>(bins);
 #pragma unroll
-    for (int j = 0; j < NL; ++j) atomicAdd(reinterpret_cast<unsigned *>(bb + tokoff[j]), (unsigned)(qt[j] + 0.5f));
+    for (int j = 0; j < NL; ++j)  // (positions beyond label_length sit out: their adds would all hit the one pad slot and serialise)
+#ifdef CTC_F6_NOVALID
+      atomicAdd(reinterpret_cast<unsigned *>(bb + tokoff[j]), (unsigned)(qt[j] + 0.5f));
+#else
+      if (valid[j]) atomicAdd(reinterpret_cast<unsigned *>(bb + tokoff[j]), (unsigned)(qt[j] + 0.5f));
+#endif
+    wave_lds_fence();  // the bins read below were written by other lanes
     const float c1 = -dl * 9.31322574615478515625e-10f;
     const float c2 = dl * inv;
 #pragma unroll
@@ -588,12 +594,14 @@ struct Rows {
 #endif
 template <int BLK, int NH, int NL>
 struct P1Split {
-  static constexpr int X = NH == 4 ? CTC_F6_X : BLK / 3, Y = NH == 4 ? CTC_F6_Y : BLK / 3;
-  static constexpr int R = NH == 4 ? BLK - 2 * X - 2 * Y : BLK - X - Y;
-  static_assert(NH == 4 || NH == 2, "helpers per side");
+  // (NH = 1, the 3-frame blocks of the 8-positions-per-lane variant: two frames for the helper, one for the recompute wavefront)
+  static constexpr int X = NH == 4 ? CTC_F6_X : NH == 2 ? BLK / 3 : 2, Y = NH == 4 ? CTC_F6_Y : NH == 2 ? BLK / 3 : 0;
+  static constexpr int R = NH == 4 ? BLK - 2 * X - 2 * Y : NH == 2 ? BLK - X - Y : BLK - X;
+  static_assert(NH == 4 || NH == 2 || NH == 1, "helpers per side");
   static_assert(X >= 0 && Y >= 0 && R >= 0 && X <= 6 && Y <= 6 && R <= 6, "phase-1 split: at most 6 frames per worker");
   static constexpr int count(int worker) {
     if (NH == 4) return worker < 2 ? X : worker < 4 ? Y : R;
+    if (NH == 1) return worker == 0 ? X : R;
     return worker == 0 ? X : worker == 1 ? Y : R;
   }
   static constexpr int first(int worker) {
@@ -768,7 +776,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
   int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
   const bool shape_ok = (ll <= p.U);
   if (!shape_ok) ll = 0;
-  const int nslot = (T + 5) / 6 + 3;  // checkpoint slots per direction (sized for the shortest block length)
+  const int nslot = (T + 2) / 3 + 3;  // checkpoint slots per direction (sized for the shortest block length)
   float *own_rows = (DIR == 0 ? alpha_ws : beta_ws) + (long)b * (T + 1) * SRS;
   const float *oth_rows = (DIR == 0 ? beta_ws : alpha_ws) + (long)b * (T + 1) * SRS;
   int *own_k = kexp_ws + ((long)b * 2 + DIR) * nslot * 64;
@@ -986,9 +994,15 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
           float *srow = RR[d] + 2 * lane * NL;
           if constexpr (NL == 1) *reinterpret_cast<float2 *>(srow) = make_float2(tok[0], qsh);
           else if constexpr (NL == 2) *reinterpret_cast<float4 *>(srow) = make_float4(qal, tok[0], tok[1], qsh);
-          else {
-            *reinterpret_cast<float4 *>(srow) = make_float4(qal, tok[0], tok[1], tok[2]);
-            *reinterpret_cast<float2 *>(srow + 4) = make_float2(tok[3], qsh);
+          else {  // NL + 2 values: [qal, tok[NL], qsh] as 16-byte pieces and one 8-byte tail
+            float sv[NL + 2];
+            sv[0] = qal; sv[NL + 1] = qsh;
+#pragma unroll
+            for (int jj = 0; jj < NL; ++jj) sv[1 + jj] = tok[jj];
+#pragma unroll
+            for (int q4 = 0; q4 < (NL + 2) / 4; ++q4)
+              *reinterpret_cast<float4 *>(srow + 4 * q4) = make_float4(sv[4 * q4], sv[4 * q4 + 1], sv[4 * q4 + 2], sv[4 * q4 + 3]);
+            *reinterpret_cast<float2 *>(srow + NL) = make_float2(sv[NL], sv[NL + 1]);
           }
           KLr[d][lane] = KL;
           if constexpr (!(KIND == 0 && DIR == 0)) S.step(e);
@@ -1052,7 +1066,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
   const int T = p.T, UP = L.UP, SRS = L.SRS;
   int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
   if (ll > p.U) ll = 0;
-  const int nslot = (T + 5) / 6 + 3;
+  const int nslot = (T + 2) / 3 + 3;
   const float *ck_rows = (RDIR == 0 ? alpha_ws : beta_ws) + (long)b * (T + 1) * SRS;
   const int *ck_k = kexp_ws + ((long)b * 2 + RDIR) * nslot * 64;
   float *dump = lds.dump[2 + SIDE];
@@ -1212,9 +1226,11 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         case 2: estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(2), SP::count(2)>(S, lds, geo, stats, sinkp, dump, lane, wave F6_ST_ARG); break;
         default: estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(3), SP::count(3)>(S, lds, geo, stats, sinkp, dump, lane, wave F6_ST_ARG); break;
       }
-    } else {
+    } else if constexpr (NH == 2) {
       if (h == 0) estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, sinkp, dump, lane, wave F6_ST_ARG);
       else estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(1), SP::count(1)>(S, lds, geo, stats, sinkp, dump, lane, wave F6_ST_ARG);
+    } else {
+      estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, sinkp, dump, lane, wave F6_ST_ARG);
     }
     // ================= meeting point =================
     __syncthreads();
@@ -1320,9 +1336,17 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
           if constexpr (NL == 1) { const float2 t = *reinterpret_cast<const float2 *>(srow); qt[0] = t.x; qsh = t.y; }
           else if constexpr (NL == 2) { const float4 t = *reinterpret_cast<const float4 *>(srow); qal = t.x; qt[0] = t.y; qt[1] = t.z; qsh = t.w; }
           else {
-            const float4 t = *reinterpret_cast<const float4 *>(srow);
-            const float2 u = *reinterpret_cast<const float2 *>(srow + 4);
-            qal = t.x; qt[0] = t.y; qt[1] = t.z; qt[2] = t.w; qt[3] = u.x; qsh = u.y;
+            float sv[NL + 2];
+#pragma unroll
+            for (int q4 = 0; q4 < (NL + 2) / 4; ++q4) {
+              const float4 t = *reinterpret_cast<const float4 *>(srow + 4 * q4);
+              sv[4 * q4] = t.x; sv[4 * q4 + 1] = t.y; sv[4 * q4 + 2] = t.z; sv[4 * q4 + 3] = t.w;
+            }
+            const float2 u = *reinterpret_cast<const float2 *>(srow + NL);
+            sv[NL] = u.x; sv[NL + 1] = u.y;
+            qal = sv[0]; qsh = sv[NL + 1];
+#pragma unroll
+            for (int jj = 0; jj < NL; ++jj) qt[jj] = sv[1 + jj];
           }
 #pragma unroll
           for (int jj = 0; jj < NL; ++jj) if (jj != JS) qt[jj] *= kl;
@@ -1510,7 +1534,10 @@ hipError_t CTC_F6_ENTRY(const Problem &p, const Layout &L, char *ws, float *loss
     if (e != hipSuccess) return e;
     perm = reinterpret_cast<const int *>(ws + L.off_perm);
   }
-#if CTC_FUSED6_NL == 4
+#if CTC_FUSED6_NL == 8
+  return p.V <= 256 ? launch6<8, 1, 3, 1>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st)
+                    : launch6<8, 1, 3, 2>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st);
+#elif CTC_FUSED6_NL == 4
   return p.V <= 256 ? launch6<4, 2, 6, 1>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st)
                     : launch6<4, 2, 6, 2>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st);
 #else

@@ -474,7 +474,7 @@ struct Side {
   __device__ __forceinline__ void grad_row(int t, const float (&s1)[NL], const float (&s2)[NL], float s0,
                                            const float4 (&xr)[VPL], const Emis<NL> &e) const {
 #pragma unroll
-    for (int q = 0; q < VPL; ++q) *reinterpret_cast<float4 *>(bins + 256 * q + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < VPL; ++q) *reinterpret_cast<uint4 *>(bins + 256 * q + lane * 4) = make_uint4(0u, 0u, 0u, 0u);  // (same type as the atomics and the read: float stores may be reordered against them)
     float qb = (lane == 0) ? fexp2(s0) : 0.f;
     float qt[NL];
 #pragma unroll
@@ -491,8 +491,9 @@ struct Side {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const unsigned qi = (unsigned)(fminf(qt[j], 1.0f) * 1073741824.0f + 0.5f);
-      atomicAdd(reinterpret_cast<unsigned *>(bb + tokoff[j]), qi);  // pad slot absorbs label positions >= label_length
+      if (tokoff[j] != 4 * V) atomicAdd(reinterpret_cast<unsigned *>(bb + tokoff[j]), qi);  // (positions >= label_length point at the pad slot: their adds would serialise on it)
     }
+    wave_lds_fence();  // the bins read below were written by other lanes
     qb = wave_sum_dpp(qb);
     // (no wave barrier needed: LDS ops of one wave execute in order and may-alias accesses keep program order)
 #pragma unroll
@@ -522,14 +523,15 @@ struct Side {
   __device__ __forceinline__ void grad_row30(int t, const float (&s1)[NL], const float (&s2)[NL], float s0,
                                              const float4 (&xr)[VPL], const Emis<NL> &e) const {
 #pragma unroll
-    for (int q = 0; q < VPL; ++q) *reinterpret_cast<float4 *>(bins + 256 * q + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < VPL; ++q) *reinterpret_cast<uint4 *>(bins + 256 * q + lane * 4) = make_uint4(0u, 0u, 0u, 0u);  // (same type as the atomics and the read: float stores may be reordered against them)
     float qb = (lane == 0) ? fexp2(s0) : 0.f;
     char *bb = reinterpret_cast<char *>(bins);
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       qb += fexp2(s1[j]);
-      atomicAdd(reinterpret_cast<unsigned *>(bb + tokoff[j]), (unsigned)(fexp2(s2[j]) + 0.5f));
+      if (tokoff[j] != 4 * V) atomicAdd(reinterpret_cast<unsigned *>(bb + tokoff[j]), (unsigned)(fexp2(s2[j]) + 0.5f));
     }
+    wave_lds_fence();  // the bins read below were written by other lanes
     qb = wave_sum_dpp(qb);  // blank posterior, in units of 2^-30
     const float c1 = -dl * 9.31322574615478515625e-10f;
 #pragma unroll

@@ -176,12 +176,12 @@ __global__ __launch_bounds__(256) void hess_slab_kernel(Problem p, Layout L, con
     }
     qb = wave_sum_dpp(qb);
     if (lane == 0) ubin[p.blank] = tofix(qb);
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
     for (int k2 = lane; k2 < V; k2 += 64) {  // base_loss.py:235-237 : -exp(.) + g (x) g
       nt_store(out + (long)t2 * V + k2, g1 * grow[(long)t2 * V + k2] - (float)ubin[k2] * 9.31322574615478515625e-10f);
       ubin[k2] = 0u;
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
   };
 
   auto fill_common = [&](auto &S) {
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256, 6) void hess_pair_kernel(Problem p, Layout L, 
   // Output rows are staged in LDS and written SR rows (SR*V*4 bytes, contiguous) at a time: with one 128-byte store per
   // row and ~10^4 slabs in flight the HBM write stream had no page locality (2.5 TB/s where a plain fill reaches 6.8).
   auto flush = [&](int lo, int hi) {  // rows lo..hi of this half's slab, lo and hi in the same aligned group of SR rows
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
 #ifdef CTC_HESS_DBG_NOSTORE
     if (have && lp == 12345.0) {
 #else
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256, 6) void hess_pair_kernel(Problem p, Layout L, 
         for (int k = hl; k < n; k += W) nt_store(dst + k, src[k]);
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
   };
   const float *grow_l = grow + hl;
   auto emit_row = [&](int t2, float s1, float s2, float s0, float gq0, float gq1) {
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256, 6) void hess_pair_kernel(Problem p, Layout L, 
     asm(CTC_HALF_REDUCE_ASM("v_add_f32_dpp") : "+v"(qb));  // lanes 31 / 63 now hold their half's sum ...
     HST(5);
     if (last) ubin[p.blank] = tofix(qb);                    // ... and write it: no broadcast needed
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
     float *srow = stage + (t2 & (SR - 1)) * V + hl;
     // base_loss.py:235-237 : -exp(.) + g (x) g ; the first two chunks use the prefetched gradient values
     if (hl < V) { srow[0] = g1 * gq0 - (float)ubin[hl] * 9.31322574615478515625e-10f; ubin[hl] = 0u; }
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(256, 6) void hess_pair_kernel(Problem p, Layout L, 
         ubin[k2 + hl] = 0u;
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
   };
 
   // =============== rows t2 > t1 : restricted alpha vector pushed forward ===============

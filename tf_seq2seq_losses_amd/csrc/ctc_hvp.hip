@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void hvp_out_kernel(Problem p, Layout L, const
   }
   float *bin = lds + (long)w * V;
   for (int k = lane; k < V; k += 64) bin[k] = 0.f;
-  __builtin_amdgcn_wave_barrier();
+  wave_lds_fence();
   constexpr int PAIR = (KIND == 0) ? 2 : 1;
   const int tailpos = PAIR * UP;
   const int32_t *lab = p.labels + (long)b * p.label_stride;
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void hvp_out_kernel(Problem p, Layout L, const
   }
   dblank = wave_sum(dblank);
   if (lane == 0) bin[p.blank] = dblank;
-  __builtin_amdgcn_wave_barrier();
+  wave_lds_fence();
   if (p.wrt == 0) {
     const float *x = p.logits + row * (long)V, *v = vec + row * (long)V;
     const float mx = emis[row * (long)L.ERS + UP + 1], l2s = emis[row * (long)L.ERS + UP + 2];

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
   unsigned *ubin = reinterpret_cast<unsigned *>(bin);
   auto tofix = [](float q) -> unsigned { return (unsigned)(fminf(q, 1.0f) * 1073741824.0f + 0.5f); };
   for (int k = lane; k < V; k += 64) ubin[k] = 0u;
-  __builtin_amdgcn_wave_barrier();
+  wave_lds_fence();
 
   const int32_t *lab = p.labels + (long)b * p.label_stride;
   const float *ra = alpha + ((long)b * (p.T + 1) + (KIND == 0 ? t + 1 : t)) * L.SRS;
@@ -479,9 +479,9 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
   }
   qblank = wave_sum(qblank);
   if (lane == 0 && p.blank >= 0 && p.blank < V) ubin[p.blank] = tofix(qblank);
-  __builtin_amdgcn_wave_barrier();
+  wave_lds_fence();
   for (int k = lane; k < V; k += 64) bin[k] = (float)ubin[k] * 9.31322574615478515625e-10f;  // back to float, in place
-  __builtin_amdgcn_wave_barrier();
+  wave_lds_fence();
 
   const float dl = d_loss ? d_loss[b] : 1.0f;
   if (p.wrt == 0) {
@@ -595,14 +595,14 @@ __global__ __launch_bounds__(256) void grad_wide_kernel(Problem p, Layout L, con
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4 *>(bins + lane * 4 + 256 * q) = make_uint4(0u, 0u, 0u, 0u);
-    __builtin_amdgcn_wave_barrier();  // (LDS operations of one wavefront execute in program order)
+    wave_lds_fence();  // (LDS operations of one wavefront execute in program order)
     for (int i = lane; i < ll; i += 64) {
       const int tok = (i < p.label_stride) ? lab[i] : p.blank;
       const unsigned r = (unsigned)(tok - c0);
       if (tok >= 0 && tok < V && tok != p.blank && r < (unsigned)CH) atomicAdd(&bins[r], qtab[i]);
     }
     if (lane == 0 && p.blank >= c0 && p.blank < c0 + CH && p.blank < V) bins[p.blank - c0] = qbfix;
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int k = c0 + lane * 4 + 256 * q;
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void grad_wide_kernel(Problem p, Layout L, con
         gput4(k, r);
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
   }
 }
 
