@@ -153,18 +153,21 @@ def secondary(device, rank):
     B, T, U, V = 256, 1000, 128, 256
     alg = B * 2 * T * V * 4
 
-    def lossgrad(name, kind_name, ragged, seed):
+    def lossgrad(name, kind_name, ragged, seed, B=B, T=T, U=U, V=V, steps=50):
         host, dev = make_inputs(B, T, U, V, seed=seed, ragged=ragged, device=device)
         step = _lossgrad_callable(lib, _lib, ops, ops.KINDS[kind_name], dev, B, T, U, V)
-        kms, wms = _events_ms(step, 50, 10)
+        kms, wms = _events_ms(step, steps, 10)
         frames = int(host["logit_length"].sum())
         out[name] = dict(workload=f"{kind_name}_ctc_loss loss+grad B={B} T={T} U={U} V={V} fp32 {'ragged' if ragged else 'full-length'}",
                          value=B / (wms * 1e-3), unit="utterances/s", ms_per_step=wms,
                          pipeline=_lib.pipeline_name(ops.KINDS[kind_name], 0, B, T, V, U, True),
-                         roofline=_roof(alg if not ragged else frames * 2 * V * 4, kms, traffic=None))
+                         roofline=_roof(frames * 2 * V * 4, kms, traffic=None))
 
     lossgrad("config3_simplified", "simplified", False, rank)
     lossgrad("classic_ragged", "classic", True, 1)
+    # shapes off the north star: long labels (eight label positions per lane) and a BPE-sized vocabulary (three-kernel pipeline)
+    lossgrad("classic_long_labels_U512", "classic", False, rank, U=512, steps=20)
+    lossgrad("classic_wide_vocabulary_V4096", "classic", False, rank, B=32, V=4096, steps=20)
 
     # the drop-in Python call: classic_ctc_loss + autograd.grad(mean(loss)) (tests/benchmark.py:195-201 of the reference)
     host, dev = make_inputs(B, T, U, V, seed=rank, ragged=False, device=device)

@@ -48,16 +48,33 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
-  return v;
+// ---- wave64 reductions with DPP (result broadcast through an SGPR) ----
+// Hand-written: hipcc lowers __builtin_amdgcn_update_dpp reductions to mov + mov_dpp + op per level (18 instructions
+// per reduction); here every level is ONE DPP-fused VALU op.  Lanes without a valid DPP source are disabled and keep
+// their value.  `s_nop 1` = the 2 wait states a DPP read of a VGPR written by the previous VALU op needs (hipcc pads
+// nothing inside asm).  After the row_shr scan lane 15 of each 16-lane row holds the row result; row_bcast:15 / :31
+// carry it into lane 63.
+#define CTC_WAVE_REDUCE_ASM(OP)                                                      \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"            \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"            \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"            \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"            \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"         \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"         \
+  "s_nop 0"
+
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  asm(CTC_WAVE_REDUCE_ASM("v_add_f32_dpp") : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-  return v;
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  asm(CTC_WAVE_REDUCE_ASM("v_max_f32_dpp") : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// wave-wide maximum / sum, the same value in every lane.  (Butterflies of __shfl_xor compile to six dependent ds_bpermute
+// round trips through the LDS crossbar, ~1 000 cycles of latency per reduction in the one-row-per-wavefront kernels.)
+__device__ __forceinline__ float wave_max(float v) { return wave_max_dpp(v); }
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 
 // One call's inputs (device pointers) and shapes.
 struct Problem {

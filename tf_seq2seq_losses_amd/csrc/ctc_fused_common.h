@@ -28,29 +28,7 @@ constexpr int NPACE = 48; // pacing stores after a ring prologue (see Side::pace
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-// ---- wave64 reductions with DPP (result broadcast through an SGPR) ----
-// Hand-written: hipcc lowers __builtin_amdgcn_update_dpp reductions to mov + mov_dpp + op per level (18 instructions
-// per reduction); here every level is ONE DPP-fused VALU op.  Lanes without a valid DPP source are disabled and keep
-// their value.  `s_nop 1` = the 2 wait states a DPP read of a VGPR written by the previous VALU op needs (hipcc pads
-// nothing inside asm).  After the row_shr scan lane 15 of each 16-lane row holds the row result; row_bcast:15 / :31
-// carry it into lane 63.
-#define CTC_WAVE_REDUCE_ASM(OP)                                                      \
-  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"            \
-  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"            \
-  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"            \
-  "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"            \
-  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"         \
-  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"         \
-  "s_nop 0"
-
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  asm(CTC_WAVE_REDUCE_ASM("v_add_f32_dpp") : "+v"(v));
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-__device__ __forceinline__ float wave_max_dpp(float v) {
-  asm(CTC_WAVE_REDUCE_ASM("v_max_f32_dpp") : "+v"(v));
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
+// (wave64 DPP reductions wave_sum_dpp / wave_max_dpp: ctc_common.h)
 __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
