@@ -43,7 +43,7 @@ inline hipError_t run_fused5(const Problem &p, const Layout &L, char *ws, float 
   }
 }
 inline bool fused6_eligible(const Problem &p, const Layout &L) { return fused5_eligible(p, L); }
-// The linear-domain kernel (ctc_fused6.hip) covers the shapes of fused5 up to 256 label positions and is followed by a fused5 launch restricted to the
+// The linear-domain kernel (ctc_fused6.hip) covers the shapes of fused5; it used to be followed by a fused5 launch restricted to the
 // utterances it flagged (dynamic range beyond float32 mantissas with per-lane exponents; normally none).
 inline hipError_t run_fused6(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
   hipError_t e;
@@ -54,8 +54,7 @@ inline hipError_t run_fused6(const Problem &p, const Layout &L, char *ws, float 
     case 8: e = p.kind == 0 ? run_fused6_classic_nl8(p, L, ws, loss, d_loss, grad, st) : run_fused6_simplified_nl8(p, L, ws, loss, d_loss, grad, st); break;
     default: return hipErrorInvalidValue;
   }
-  if (e != hipSuccess) return e;
-  return run_fused5(p, L, ws, loss, d_loss, grad, true, st);
+  return e;  // (flagged utterances are redone in the log domain inside the same launch: ctc_fused6.hip, end of fused6_kernel)
 }
 // shapes the two-wavefront fused kernel (ctc_fused.hip) is instantiated for: logits input, V in {256, 512, 1024}, U <= 256
 inline bool fused_eligible(const Problem &p, const Layout &L) {

@@ -40,6 +40,7 @@
 // 420-468, tools.py:27-40.
 #include "ctc_fused_common.h"
 #include "ctc_swap_reduce.h"
+#include "ctc_fused5_roles.h"  // the log-domain roles: run inside this kernel for the utterances it flags
 
 #ifndef CTC_FUSED_KIND
 #error "compile with -DCTC_FUSED_KIND=0 (classic) or 1 (simplified)"
@@ -1444,7 +1445,12 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused6_kernel(Problem p, La
                                                                     const float *__restrict__ d_loss,
                                                                     float *__restrict__ grad, int *__restrict__ flag_ws,
                                                                     int2 *__restrict__ meet_ws, const int *__restrict__ perm) {
-  __shared__ __attribute__((aligned(16))) Lds<KIND, NL, NH, BLK, VPL> lds;
+  // (the log-domain roles reuse the LDS once the linear-domain ones are done with it)
+  __shared__ __attribute__((aligned(16))) union LdsBoth {
+    Lds<KIND, NL, NH, BLK, VPL> lin;
+    fused5::Lds<KIND, NL, NH, BLK, VPL> log;
+  } both;
+  Lds<KIND, NL, NH, BLK, VPL> &lds = both.lin;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = perm ? perm[blockIdx.x] : (int)blockIdx.x;
   Geo<BLK> geo;
@@ -1475,6 +1481,16 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused6_kernel(Problem p, La
     run_helper<KIND, NL, NH, BLK, VPL, 0, XT>(p, L, stats_ws, sink_ws, d_loss, grad, lds, geo, w - 4, b, flag_ws);
   } else {
     run_helper<KIND, NL, NH, BLK, VPL, 1, XT>(p, L, stats_ws, sink_ws, d_loss, grad, lds, geo, w - 4 - NH, b, flag_ws);
+  }
+  // Utterances the linear domain cannot hold (flags D1..D6, normally none): the same wavefronts redo them in the log
+  // domain right here -- same roles, the LDS reused, every output row rewritten -- instead of a second launch that
+  // finds nothing to do (4.5 us per call).  In a gradient-resume call the flag is the one the loss-only call left.
+  __syncthreads();
+  const int fl = lds.flag;
+  __syncthreads();
+  if (fl != 0) {
+    __builtin_amdgcn_s_setprio(0);
+    fused5::run_roles<KIND, NL, NH, BLK, VPL, XT>(p, L, alpha_ws, beta_ws, logp_ws, stats_ws, loss, d_loss, grad, sink_ws, both.log, w, b);
   }
 }
 
