@@ -359,7 +359,7 @@ def main():
             traffic = traffic_src = None
         else:
             pipeline = _lib.pipeline_name(kind, _lib.WRT_LOGITS, B, T, V, U, True)
-            kernel_name = {"fused6": "fused6_kernel (one launch: linear-domain chains + recompute chains + helpers) + the fused5_kernel launch for flagged utterances (none here)",
+            kernel_name = {"fused6": "fused6_kernel (one launch: linear-domain chains + recompute chains + helpers; flagged utterances are redone in the log domain inside it, none here)",
                            "fused5": "fused5_kernel (one launch: chains + recompute chains + helpers)",
                            "fused2": "fused_kernel",
                            "v1": "emit_kernel + scan_kernel + grad_kernel"}[pipeline] + " = one ctc_amd_loss_grad call"
