@@ -98,6 +98,29 @@ def test_benign_shapes_of_every_vocabulary_tier_stay_on_the_linear_kernel(kind, 
     assert (np.abs(loss[:3].cpu().numpy() - rl) / rl).max() < 1e-6
 
 
+@pytest.mark.parametrize("kind,T,U", [("classic", 1000, 512), ("simplified", 1000, 400), ("classic", 700, 300)])
+def test_long_labels_on_the_linear_kernel_at_full_length(kind, T, U):
+    """257..512 label positions (eight per lane, 3-frame blocks) at T = 1000: unflagged, 1e-4 against the float64 oracle
+    (measured 1e-6), and the two-call form gives the same bits."""
+    from tf_seq2seq_losses_amd import ops, _lib
+    k = ops.KINDS[kind]
+    B, V = 3, 256
+    logits, labels, ll, tl = _case(B, T, U, V, seed=5, ragged=False)
+    ll[1] = U - 37
+    tl[2] = T - 111
+    p = ops.Prepared(_t(labels), _t(logits), _t(ll), _t(tl), 0, U=U)
+    assert _lib.pipeline_name(k, 0, B, T, V, U, True) == "fused6"
+    ws = torch.zeros(_lib.workspace_bytes(_lib.WS_LOSS_GRAD, k, B, T, V, U), dtype=torch.uint8, device=_dev())
+    loss, grad = ops.loss_grad(k, _lib.WRT_LOGITS, p, True, workspace=ws)
+    assert not _flags(ws, k, B, T, V, U).any()
+    rl, rg = C.loss_grad(kind, labels, logits, ll, tl, 0)
+    assert np.abs(grad.cpu().numpy() - rg).max() < 1e-5
+    assert (np.abs(loss.cpu().numpy() - rl) / rl).max() < 1e-6
+    loss2, ws2 = ops.loss_forward(k, _lib.WRT_LOGITS, p)
+    grad2 = ops.grad_resume(k, _lib.WRT_LOGITS, p, loss2, ws2)
+    assert torch.equal(loss, loss2) and torch.equal(grad, grad2)
+
+
 @pytest.mark.parametrize("kind", ["classic", "simplified"])
 def test_linear_kernel_flags_what_it_cannot_hold_and_nothing_else(kind):
     """Benign logits (N(0,1), the benchmark distribution): no utterance is flagged and the gradient is the float64 one to

@@ -52,9 +52,16 @@ namespace fused6 {
 using namespace ctc::fused;
 
 constexpr int DEAD = -(1 << 24);  // exponent of a lane whose mantissas are all zero
-constexpr int GAP = 16;           // a dead lane adopts its upstream neighbour's exponent minus GAP
-constexpr int DOWN_MAX = 64;      // D3
-constexpr int DECAY_MAX = 64;     // D4
+constexpr int GAP = 16;           // a dead lane adopts its upstream neighbour's exponent minus GAP (per adoption level)
+constexpr int GAP_WIDE = 64;      // ... when ONE level suffices (a lane of 4 or 8 label positions is never crossed within a period):
+                                  // neighbouring lanes then differ by 2^100 and more on benign inputs, and lifting a lane to
+                                  // 2^-16 of its neighbour pushed its own values towards the float32 underflow (D4)
+// D3 / D4: a lane's own values pushed 2^-96 below its exponent (by a larger inflow scale / by decay).  A float32 mantissa
+// holds them down to 2^-126, so nothing is lost yet; the margin is for what happens before the next renormalisation.  (64
+// was too tight once a lane spans eight label positions: neighbouring lanes then differ by more than 2^64 on benign inputs
+// and every loss-only call at U > 256 went to the log domain.)
+constexpr int DOWN_MAX = 96;      // D3
+constexpr int DECAY_MAX = 96;     // D4
 constexpr int KK_MAX = 90;        // D5: posterior scale 2^KK_MAX at most.  The posterior of a state is (alpha mantissa)(beta
                                   // mantissa) 2^(kA + kB - log2 P); the mantissa PRODUCT underflows below 2^-126, which is harmless
                                   // while the scale stays below 2^90 (the lost term is < 2^-5 units of 2^-30) and fatal beyond --
@@ -355,7 +362,7 @@ struct Chain {
     // serve lanes without mass, which need an exponent before the front reaches them (wave-uniform branch)
     {
       const int nb = (DIR == 0) ? from_prev_lane_i(kn, ex) : from_next_lane_i(kn, ex);
-      kn = imax(kn, nb - GAP);
+      kn = imax(kn, nb - (LV == 1 ? GAP_WIDE : GAP));
     }
     if (__builtin_amdgcn_ballot_w64(!live && relevant) != 0) {
 #pragma unroll
