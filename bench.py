@@ -275,6 +275,9 @@ def main():
         loss = torch.empty(B, dtype=torch.float32, device=device)
         grad = torch.empty((B, T, V), dtype=torch.float32, device=device)
         lib = _lib.load()
+        # sum(loss) and the finite count of a step, accumulated by the loss kernel itself in fixed point: three int64[2] buffers
+        # in rotation (step i fills i mod 3 and clears (i+1) mod 3; the collective of step i-1 may still be reading (i-1) mod 3)
+        sums = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(3)]
         native = args.dtype != "f32" or args.time_major
         if native:  # producer formats through ctc_amd_loss_grad_ex: no conversion pass anywhere
             xf = dev["logits"].to(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
@@ -291,6 +294,14 @@ def main():
                 if rc:
                     _lib.check(rc, "ctc_amd_loss_grad_ex")
                 return loss
+
+            def step_sum(k):  # the same call + sum(loss) accumulated inside the launch (ctc_amd_loss_grad_sum)
+                a = ex_args
+                rc = lib.ctc_amd_loss_grad_sum(*a[:21], sums[k].data_ptr(), sums[(k + 1) % 3].data_ptr(), a[21], a[22],
+                                               torch.cuda.current_stream().cuda_stream)
+                if rc:
+                    _lib.check(rc, "ctc_amd_loss_grad_sum")
+                return sums[k]
         else:
             args_c = prep.common(kind, _lib.WRT_LOGITS) + (loss.data_ptr(), grad.data_ptr(), None, ws.data_ptr(), ws.numel())
 
@@ -299,6 +310,17 @@ def main():
                 if rc:
                     _lib.check(rc, "ctc_amd_loss_grad")
                 return loss
+            x_ = dev["logits"]
+            sum_args = (kind, _lib.WRT_LOGITS, x_.data_ptr(), _lib.F32, x_.stride(0), x_.stride(1), prep.labels.data_ptr(), prep.stride,
+                        prep.label_length.data_ptr(), prep.logit_length.data_ptr(), 0, B, T, V, U, loss.data_ptr(), grad.data_ptr(),
+                        _lib.F32, grad.stride(0), grad.stride(1), None)
+
+            def step_sum(k):  # the same call + sum(loss) accumulated inside the launch (ctc_amd_loss_grad_sum)
+                rc = lib.ctc_amd_loss_grad_sum(*sum_args, sums[k].data_ptr(), sums[(k + 1) % 3].data_ptr(), ws.data_ptr(), ws.numel(),
+                                               torch.cuda.current_stream().cuda_stream)
+                if rc:
+                    _lib.check(rc, "ctc_amd_loss_grad_sum")
+                return sums[k]
         alg_bytes = B * 2 * T * V * (2 if args.dtype == "bf16" else 4)
 
     # The reduced scalars are read one step later (a training loop logs them), so the all-reduce of step i is issued
@@ -322,11 +344,13 @@ def main():
     # (every 4th launch carries the pair, so that event recording does not perturb the step time it is part of)
     KEV = 4
     kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((args.steps + KEV - 1) // KEV)]
+    in_kernel_sum = not args.hessian
+
     def timed_step():
         i = timed_step.i
         if i % KEV == 0:
             kev[i // KEV][0].record()
-        loss_t = step()
+        loss_t = step_sum(i % 3) if in_kernel_sum else step()
         if i % KEV == 0:
             kev[i // KEV][1].record()
         timed_step.i += 1
@@ -334,8 +358,11 @@ def main():
     timed_step.i = 0
     t0 = time.perf_counter()
     ev0.record()
-    # one ctc_amd_reduce_loss launch + (N > 1) one asynchronous all-reduce of [sum(loss), #finite] per step
-    cdist.pipelined_steps(timed_step, args.steps)
+    # per step: ONE launch (loss + gradient + the [sum(loss), #finite] pair, ctc_amd_loss_grad_sum) + (N > 1) one asynchronous
+    # all-reduce of the pair; the Hessian workload keeps the separate ctc_amd_reduce_loss launch
+    seen = []
+    cdist.pipelined_steps(timed_step, args.steps, reduced=in_kernel_sum,
+                          consume=(lambda i, pair: seen.append(pair) if i == args.steps - 1 else None) if in_kernel_sum else None)
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -343,6 +370,11 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
+    if in_kernel_sum and world == 1 and seen:  # (outside the timed region) the pair the kernel accumulated is the sum of its losses
+        fin = torch.isfinite(loss)
+        want = float(loss[fin].double().sum())
+        got, cnt = float(seen[0][0]) / 1048576.0, int(seen[0][1])
+        assert cnt == int(fin.sum()) and abs(got - want) <= 1e-6 * max(1.0, abs(want)) + B * 1e-6, (got, want, cnt)
     tmax = torch.tensor([wall], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -173,6 +173,26 @@ int ctc_amd_loss_grad_ex(int kind, int wrt,
                          void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * ctc_amd_loss_grad_ex that also accumulates what a training loop takes from the losses, without a launch of its own.
+ * Replaces: tf.reduce_sum / reduce_mean of the loss over the finite samples (README.md:62, tests/benchmark.py:199).
+ *   sum2[0] += sum over the finite loss[b] of round(loss[b] * 2^20)   (int64, fixed point: integer adds give the same
+ *              bits whatever order the workgroups finish in -- and whatever order ranks are all-reduced in)
+ *   sum2[1] += number of finite loss[b]
+ *   sum2 must hold zeros on entry (or a running total the caller wants to extend); zero_next, if not NULL, points at the
+ *   two int64 of the NEXT step and is cleared by this call -- alternate two buffers and nothing ever needs a memset.
+ * The linear-domain fused kernel adds inside its one launch; the other pipelines append one small launch.
+ * Everything else as ctc_amd_loss_grad_ex.
+ */
+int ctc_amd_loss_grad_sum(int kind, int wrt,
+                          const void *logits, int logits_dtype, int64_t logits_stride_b, int64_t logits_stride_t,
+                          const int32_t *labels, int label_stride,
+                          const int32_t *label_length, const int32_t *logit_length, int blank_index,
+                          int B, int T, int V, int U,
+                          float *loss, void *grad, int grad_dtype, int64_t grad_stride_b, int64_t grad_stride_t,
+                          const float *d_loss, long long *sum2, long long *zero_next,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Second half of a forward -> backward pair: the gradient for a loss that ctc_amd_loss_grad / ctc_amd_loss_grad_ex has just
  * computed with grad == NULL, weighted by d_loss (which a training loop only knows once the backward pass runs).
  * Replaces: forward_fn.backprop (base_loss.py:150-153) when the forward pass has already run.

@@ -147,6 +147,13 @@ def test_linear_kernel_flags_what_it_cannot_hold_and_nothing_else(kind):
     ws = torch.zeros(_lib.workspace_bytes(_lib.WS_LOSS_GRAD, k, 6, T, V, U), dtype=torch.uint8, device=_dev())
     loss, grad = ops.loss_grad(k, _lib.WRT_LOGITS, p, True, workspace=ws)
     assert _flags(ws, k, 6, T, V, U).all()
+    # the in-launch loss sum when utterances are flagged late (phase 2) or early: what was added at the meeting point is taken
+    # back and the log-domain loss added instead
+    sum2 = torch.zeros(2, dtype=torch.int64, device=_dev())
+    loss_s, _ = ops.loss_grad_sum(k, _lib.WRT_LOGITS, p, sum2)
+    fin_s = torch.isfinite(loss_s)
+    assert torch.equal(loss_s, loss)
+    assert int(sum2[1]) == int(fin_s.sum()) and int(sum2[0]) == int(torch.round(loss_s[fin_s].double() * 1048576.0).sum())
     rl, rg = C.loss_grad(kind, labels6, hard, ll[:6], tl[:6], 0)
     fin = np.isfinite(rl)
     ln = loss.cpu().numpy()
@@ -271,3 +278,33 @@ def test_wide_vocabulary_blank_in_a_later_pass(kind):
     assert (np.abs(loss.cpu().numpy() - rl) / np.abs(rl)).max() < 1e-5
     assert np.abs(grad.cpu().numpy() - rg).max() < TOL
     assert not grad[1, T - 4:].any()
+
+
+@pytest.mark.parametrize("pipeline", ["", "fused5", "v1"])
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_loss_sum_accumulated_inside_the_launch(kind, pipeline):
+    """ctc_amd_loss_grad_sum: [sum of the finite losses in units of 2^-20, their number] added to an int64 pair by the loss
+    kernel itself (fused tier) or one small launch behind it (other tiers); infeasible utterances are left out; the buffer
+    of the next step is cleared; a second call extends the running total."""
+    from tf_seq2seq_losses_amd import ops, _lib
+    k = ops.KINDS[kind]
+    B, T, U, V = 9, 60, 20, 40
+    logits, labels, ll, tl = _case(B, T, U, V, seed=8, ragged=True)
+    tl[3] = 5; ll[3] = 20          # infeasible: loss = +inf, not summed, not counted
+    p = ops.Prepared(_t(labels), _t(logits), _t(ll), _t(tl), 0, U=U)
+    sum2 = torch.zeros(2, dtype=torch.int64, device=_dev())
+    nxt = torch.full((2,), 12345, dtype=torch.int64, device=_dev())
+    _lib.debug_override("pipeline", pipeline)
+    try:
+        loss, grad = ops.loss_grad_sum(k, _lib.WRT_LOGITS, p, sum2, nxt)
+        loss_b, grad_b = ops.loss_grad(k, _lib.WRT_LOGITS, p, True)
+        ops.loss_grad_sum(k, _lib.WRT_LOGITS, p, sum2, None, want_grad=False)
+    finally:
+        _lib.debug_override("pipeline", "")
+    assert torch.equal(loss, loss_b) and torch.equal(grad, grad_b)
+    fin = torch.isfinite(loss)
+    assert not fin[3] and fin.sum() == B - 1
+    fixed = torch.round(loss[fin].double() * 1048576.0).sum()
+    assert int(sum2[1]) == 2 * (B - 1) and int(sum2[0]) == 2 * int(fixed)
+    assert nxt.tolist() == [0, 0]
+    assert abs(int(sum2[0]) * ops.LOSS_SUM_SCALE / 2 - float(loss[fin].sum())) < 1e-3

@@ -41,6 +41,11 @@ SIGNATURES = {
                                       _c_int, _c_int, _c_int, _c_int,                                   # B, T, V, U
                                       _c_void_p, _c_void_p, _c_int, ctypes.c_int64, ctypes.c_int64,    # loss, grad, dtype, strides
                                       _c_void_p, _c_void_p, _c_size_t, _c_void_p]),                     # d_loss, ws, bytes, stream
+    "ctc_amd_loss_grad_sum": (_c_int, [_c_int, _c_int, _c_void_p, _c_int, ctypes.c_int64, ctypes.c_int64,
+                                       _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int,
+                                       _c_int, _c_int, _c_int, _c_int,
+                                       _c_void_p, _c_void_p, _c_int, ctypes.c_int64, ctypes.c_int64,
+                                       _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),  # d_loss, sum2, zero_next, ws, bytes, stream
     "ctc_amd_grad_resume": (_c_int, [_c_int, _c_int, _c_void_p, _c_int, ctypes.c_int64, ctypes.c_int64,
                                      _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int,
                                      _c_int, _c_int, _c_int, _c_int,

@@ -10,6 +10,7 @@
 namespace ctc {
 hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *loss, int ndir, hipStream_t st);
 hipError_t run_grad(const Problem &p, const Layout &L, char *ws, const float *d_loss, float *grad, hipStream_t st);
+hipError_t run_sum_loss_fixed(const float *loss, int B, long long *acc, long long *zero_next, hipStream_t st);
 hipError_t run_convert(const Problem &p, const Layout &L, char *ws, float *alpha_out, float *beta_out, hipStream_t st);
 hipError_t run_fused_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 hipError_t run_fused_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
@@ -217,6 +218,10 @@ static int loss_grad_impl(ctc::Problem p, float *loss, void *grad, const float *
                   : (pl[5] == '5') ? ctc::run_fused5(p, L, wsb, loss, d_loss, gradf, false, st)
                                    : ctc::run_fused(p, L, wsb, loss, d_loss, gradf, st);
     if (ef != hipSuccess) return hip_fail(ef, pl);
+    if (p.sum_out && pl[5] != '6') {  // (fused6 adds inside its launch)
+      ef = ctc::run_sum_loss_fixed(loss, p.B, p.sum_out, p.sum_zero, st);
+      if (ef != hipSuccess) return hip_fail(ef, "loss sum launch");
+    }
     return CTC_AMD_OK;
   }
   hipError_t e = ctc::run_emit_scan(p, L, static_cast<char *>(workspace), loss, grad ? 2 : 1, st);
@@ -224,6 +229,10 @@ static int loss_grad_impl(ctc::Problem p, float *loss, void *grad, const float *
   if (grad) {
     e = ctc::run_grad(p, L, static_cast<char *>(workspace), d_loss, gradf, st);
     if (e != hipSuccess) return hip_fail(e, "grad launch");
+  }
+  if (p.sum_out) {
+    e = ctc::run_sum_loss_fixed(loss, p.B, p.sum_out, p.sum_zero, st);
+    if (e != hipSuccess) return hip_fail(e, "loss sum launch");
   }
   return CTC_AMD_OK;
 }
@@ -258,6 +267,34 @@ int ctc_amd_loss_grad_ex(int kind, int wrt, const void *logits, int logits_dtype
                                 blank_index, B, T, V, U);
   p.xsb = logits_stride_b; p.xst = logits_stride_t; p.xdtype = logits_dtype;
   p.gsb = grad_stride_b; p.gst = grad_stride_t; p.gdtype = grad_dtype;
+  return loss_grad_impl(p, loss, grad, d_loss, workspace, workspace_bytes, stream);
+}
+
+int ctc_amd_loss_grad_sum(int kind, int wrt, const void *logits, int logits_dtype, int64_t logits_stride_b,
+                          int64_t logits_stride_t, const int32_t *labels, int label_stride, const int32_t *label_length,
+                          const int32_t *logit_length, int blank_index, int B, int T, int V, int U, float *loss, void *grad,
+                          int grad_dtype, int64_t grad_stride_b, int64_t grad_stride_t, const float *d_loss, long long *sum2,
+                          long long *zero_next, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = check_common(kind, wrt, static_cast<const float *>(logits), labels, label_stride, label_length, logit_length,
+                        blank_index, B, T, V, U);
+  if (rc) return rc;
+  if (!sum2) return fail(CTC_AMD_EINVAL, "null sum2 pointer");
+  if ((logits_dtype != CTC_AMD_F32 && logits_dtype != CTC_AMD_BF16) || (grad_dtype != CTC_AMD_F32 && grad_dtype != CTC_AMD_BF16))
+    return fail(CTC_AMD_EINVAL, "dtype must be CTC_AMD_F32 or CTC_AMD_BF16 (logits %d, grad %d)", logits_dtype, grad_dtype);
+  if (logits_stride_t < V || logits_stride_b < V || (grad && (grad_stride_t < V || grad_stride_b < V)))
+    return fail(CTC_AMD_EINVAL, "strides smaller than a row of V=%d elements", V);
+  ctc::Problem p = make_problem(kind, wrt, static_cast<const float *>(logits), labels, label_stride, label_length, logit_length,
+                                blank_index, B, T, V, U);
+  p.xsb = logits_stride_b; p.xst = logits_stride_t; p.xdtype = logits_dtype;
+  p.gsb = grad_stride_b; p.gst = grad_stride_t; p.gdtype = grad_dtype;
+  p.sum_out = sum2; p.sum_zero = zero_next;
+  if (B == 0) {  // nothing to add; the next step's buffer still has to be cleared
+    if (zero_next) {
+      hipError_t e = ctc::run_sum_loss_fixed(loss, 0, sum2, zero_next, static_cast<hipStream_t>(stream));
+      if (e != hipSuccess) return hip_fail(e, "loss sum launch");
+    }
+    return CTC_AMD_OK;
+  }
   return loss_grad_impl(p, loss, grad, d_loss, workspace, workspace_bytes, stream);
 }
 

@@ -76,6 +76,14 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 __device__ __forceinline__ float wave_max(float v) { return wave_max_dpp(v); }
 __device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 
+// [0] += v in units of 2^-20 (finite v only), [1] += 1: integer atomics, so the total does not depend on the order
+__device__ __forceinline__ void add_loss_fixed(long long *acc, float v, int sign = 1) {
+  if ((v - v) == 0.f) {
+    atomicAdd(reinterpret_cast<unsigned long long *>(acc), (unsigned long long)((long long)sign * __float2ll_rn(v * 1048576.0f)));
+    atomicAdd(reinterpret_cast<unsigned long long *>(acc) + 1, (unsigned long long)(long long)sign);
+  }
+}
+
 // One call's inputs (device pointers) and shapes.
 struct Problem {
   const float *logits;
@@ -88,6 +96,9 @@ struct Problem {
   // as contiguous float32 [B,T,V].
   long xsb, xst, gsb, gst;
   int xdtype, gdtype;
+  // ctc_amd_loss_grad_sum: [0] += sum of the finite losses in units of 2^-20 (integer adds: the same bits whatever the order),
+  // [1] += their number; sum_zero (the buffer of the NEXT step, if any) is cleared by this call
+  long long *sum_out = nullptr, *sum_zero = nullptr;
   // 1: second half of a two-call loss -> gradient sequence (ctc_amd_grad_resume): the workspace still holds what the
   // loss-only call left (checkpoints, softmax statistics, log P, flags); only the linear-domain fused kernel uses it
   int resume = 0;

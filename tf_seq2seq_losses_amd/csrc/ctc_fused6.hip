@@ -137,6 +137,8 @@ struct Lds {
   int feasible;             // 1: phase 2 runs
   int lp_int;               // posterior scale: 2^-lp_int * cf = 1 / (P in mantissa units)
   float cf;
+  float lossval;            // loss[b] as written at the meeting point and whether it has been added to the running sum there
+  int added;                // (ctc_amd_loss_grad_sum; an utterance flagged later takes it back at the end of the kernel)
 };
 
 // Block geometry shared by every wavefront of the workgroup (identical to ctc_fused5.hip).
@@ -884,6 +886,11 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
       const double dlogp = (double)flog2(s) + (double)EX - sl2;
       logp_ws[b] = okP ? dlogp : -INFINITY;
       loss[b] = okP ? (float)(-dlogp * LN2_D) : INFINITY;
+      lds.lossval = okP ? (float)(-dlogp * LN2_D) : INFINITY;
+      // sum(loss) for the training loop (ctc_amd_loss_grad_sum): added HERE, mid-kernel, fire and forget -- at the end of the
+      // kernel the two atomics of 256 workgroups finishing together cost 3.6 us
+      lds.added = (p.sum_out != nullptr && fl == 0);
+      if (lds.added) add_loss_fixed(p.sum_out, lds.lossval);
       const int fe = frexp_e(s);
       lds.lp_int = EX + fe;
       lds.cf = __builtin_amdgcn_rcpf(ldexp_f(s, -fe));   // 1 / mantissa, in (1, 2]
@@ -1463,7 +1470,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused6_kernel(Problem p, La
   Geo<BLK> geo;
   geo.init(clampi(p.logit_length[b], 0, p.T));
   if (threadIdx.x == 0) {
-    lds.flag = 0; lds.feasible = 0;
+    lds.flag = 0; lds.feasible = 0; lds.lossval = INFINITY; lds.added = 0;
     if (p.resume) {  // the loss-only call left the outcome of the meeting point in the workspace
       const int f = flag_ws[b];
       const int2 m = meet_ws[b];
@@ -1494,11 +1501,20 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused6_kernel(Problem p, La
   // finds nothing to do (4.5 us per call).  In a gradient-resume call the flag is the one the loss-only call left.
   __syncthreads();
   const int fl = lds.flag;
+  const float lossval = lds.lossval;
+  const int added = lds.added;
   __syncthreads();
   if (fl != 0) {
     __builtin_amdgcn_s_setprio(0);
     fused5::run_roles<KIND, NL, NH, BLK, VPL, XT>(p, L, alpha_ws, beta_ws, logp_ws, stats_ws, loss, d_loss, grad, sink_ws, both.log, w, b);
   }
+  // sum(loss) for the training loop, without a launch of its own (ctc_amd_loss_grad_sum): the thread that wrote loss[b] --
+  // lane 0 of main chain A in either domain -- adds it in fixed point; the second call of a loss / gradient pair adds nothing
+  if (p.sum_out != nullptr && !p.resume && threadIdx.x == 0 && fl != 0) {  // redone in the log domain: its loss, not the first one
+    if (added) add_loss_fixed(p.sum_out, lossval, -1);
+    add_loss_fixed(p.sum_out, loss[b]);
+  }
+  if (p.sum_zero != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { p.sum_zero[0] = 0; p.sum_zero[1] = 0; }
 }
 
 }  // namespace fused6

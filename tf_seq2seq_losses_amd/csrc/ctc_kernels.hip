@@ -832,6 +832,16 @@ static __global__ __launch_bounds__(256) void reduce_loss_kernel(const float *__
   __syncthreads();
   if (threadIdx.x == 0) { out[0] = (ss[0] + ss[1]) + (ss[2] + ss[3]); out[1] = (sn[0] + sn[1]) + (sn[2] + sn[3]); }
 }
+// the same pair as add_loss_fixed accumulates inside fused6_kernel, for the pipelines that do not (one small launch)
+static __global__ __launch_bounds__(256) void sum_loss_fixed_kernel(const float *__restrict__ loss, int B, long long *__restrict__ acc,
+                                                                     long long *__restrict__ zero_next) {
+  for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) add_loss_fixed(acc, loss[b]);
+  if (zero_next != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { zero_next[0] = 0; zero_next[1] = 0; }
+}
+hipError_t run_sum_loss_fixed(const float *loss, int B, long long *acc, long long *zero_next, hipStream_t st) {
+  hipLaunchKernelGGL(sum_loss_fixed_kernel, dim3(B <= 256 ? 1 : (B + 255) / 256 > 64 ? 64 : (B + 255) / 256), dim3(256), 0, st, loss, B, acc, zero_next);
+  return hipGetLastError();
+}
 hipError_t run_reduce_loss(const float *loss, int B, float *out, hipStream_t st) {
   hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, st, loss, B, out);
   return hipGetLastError();

@@ -54,20 +54,39 @@ def all_reduce_pair(local_loss: torch.Tensor, group=None, async_op: bool = False
     return buf, (work if async_op else None)
 
 
-def pipelined_steps(step: Callable[[], torch.Tensor], steps: int, group=None):
+def pipelined_steps(step: Callable[[], torch.Tensor], steps: int, group=None, reduced: bool = False,
+                    consume: Callable[[int, torch.Tensor], None] = None):
     """The data-parallel loop of bench.py: every step computes this rank's losses and issues the all-reduce of its
     [sum, count] pair asynchronously; the pair of step i-1 is waited for after step i has been launched, so the
-    collective (two floats, latency-bound) runs beside the next kernel.  Returns the list of reduced pairs, all
-    complete on return."""
+    collective (two numbers, latency-bound) runs beside the next kernel.  Returns the list of reduced pairs, all
+    complete on return.
+
+    reduced=True: `step()` returns this rank's pair itself -- the int64[2] buffer ctc_amd_loss_grad_sum accumulated inside
+    the loss kernel (fixed point: the all-reduced total has the same bits whatever the order) -- and no reduction launch is
+    left on the stream.  The caller cycles THREE such buffers: step i fills buffer i mod 3 and clears buffer (i+1) mod 3,
+    last used by step i-2, whose collective has been waited for by then.  `consume(i, pair)` is called once the pair of
+    step i is complete and before its buffer is recycled; in this mode the returned list is empty."""
     out, pending = [], None
-    for _ in range(steps):
-        buf, work = all_reduce_pair(step(), group=group, async_op=True)
-        if pending is not None and pending[1] is not None:
+    for i in range(steps):
+        if reduced:
+            buf, work = step(), None
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        else:
+            buf, work = all_reduce_pair(step(), group=group, async_op=True)
+        if pending is not None:
+            if pending[1] is not None:
+                pending[1].wait()
+            if consume is not None:
+                consume(pending[2], pending[0])
+        pending = (buf, work, i)
+        if not reduced:
+            out.append(buf)
+    if pending is not None:
+        if pending[1] is not None:
             pending[1].wait()
-        pending = (buf, work)
-        out.append(buf)
-    if pending is not None and pending[1] is not None:
-        pending[1].wait()
+        if consume is not None:
+            consume(pending[2], pending[0])
     return out
 
 

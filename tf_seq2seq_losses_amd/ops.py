@@ -152,6 +152,34 @@ def loss_grad(kind: int, wrt: int, p: Prepared, want_grad: bool, d_loss: Optiona
     return loss, grad
 
 
+LOSS_SUM_SCALE = 1.0 / 1048576.0  # unit of the fixed-point loss sum (ctc_amd_loss_grad_sum)
+
+
+def loss_grad_sum(kind: int, wrt: int, p: Prepared, sum2: torch.Tensor, zero_next: Optional[torch.Tensor] = None,
+                  want_grad: bool = True, d_loss: Optional[torch.Tensor] = None):
+    """loss_grad that also adds [sum of the finite losses in units of 2^-20, their number] to the int64[2] tensor `sum2`
+    inside the same launch (exact integer adds: deterministic) and clears `zero_next` for the following step."""
+    lib = _lib.load()
+    assert sum2.dtype == torch.int64 and sum2.numel() == 2 and sum2.device == p.device
+    loss = torch.empty(p.B, dtype=torch.float32, device=p.device)
+    if p.native:
+        grad = torch.empty_strided(p.x.shape, p.x.stride(), dtype=p.x.dtype, device=p.device) if want_grad else None
+    else:
+        grad = torch.empty((p.B, p.T, p.V), dtype=torch.float32, device=p.device) if want_grad else None
+    ws = _workspace(_lib.WS_LOSS_GRAD, kind, p)
+    if d_loss is not None:
+        d_loss = d_loss.to(device=p.device, dtype=torch.float32).contiguous()
+    dt = _DTYPES[p.x.dtype]
+    gs = (grad.stride(0), grad.stride(1)) if grad is not None else (p.T * p.V, p.V)
+    with _on_device(p.device):
+        rc = lib.ctc_amd_loss_grad_sum(kind, wrt, _ptr(p.x), dt, p.x.stride(0), p.x.stride(1), _ptr(p.labels), p.stride,
+                                       _ptr(p.label_length), _ptr(p.logit_length), p.blank, p.B, p.T, p.V, p.U,
+                                       _ptr(loss), _ptr(grad), dt, gs[0], gs[1], _ptr(d_loss), _ptr(sum2), _ptr(zero_next),
+                                       ws.data_ptr(), ws.numel(), _stream(p.device))
+    _lib.check(rc, "ctc_amd_loss_grad_sum")
+    return loss, grad
+
+
 def loss_forward(kind: int, wrt: int, p: Prepared) -> Tuple[torch.Tensor, torch.Tensor]:
     """Loss only, with a workspace of its own that grad_resume continues from (returned; keep it alive until then)."""
     n = _WS_BYTES.get((_lib.WS_LOSS_GRAD, kind, p.B, p.T, p.V, p.U))
