@@ -23,7 +23,9 @@
 //   8 bytes of softmax statistics per frame: ~1.55x the algorithmic 2*T*V*4 bytes (ctc_fused4.hip: 2.5x, v1: 4.4x).
 //
 // References: classic_ctc_loss.py:310-462,565-669, simplified_ctc_loss.py:291-438,456-534, base_loss.py:262-298,328-344,
-// 420-468, tools.py:27-40.  Eligibility: V <= 256, U <= 128 (LDS budget); otherwise ctc_fused.hip / the v1 pipeline run.
+// 420-468, tools.py:27-40.  Eligibility (fused5_eligible in ctc_capi.hip): logits input, V <= 512 with U <= 512 or V <= 1024 with
+// U <= 128 (LDS budget); otherwise ctc_fused.hip / the v1 pipeline run.  The roles live in ctc_fused5_roles.h (shared with
+// ctc_fused6.hip, which runs them inside its own launch for the utterances it flags).
 // Instantiated per input/output format XT (Side in ctc_fused_common.h): contiguous float32, strided float32, bfloat16,
 // and float32 rows that are not 16-byte aligned.  With grad == NULL every role returns at the meeting point (loss only).
 #include "ctc_fused5_roles.h"
