@@ -206,3 +206,8 @@ if __name__ == "__main__":
                 run(kind, 256, 1000, U, 256, seed=1, ncheck=2, reps=20)
         run("classic", 64, 2000, 512, 256, seed=1, ncheck=1, reps=5)
         run("classic", 256, 1000, 512, 512, seed=1, ncheck=1, reps=10)
+    if which == "longT":
+        for kind in ("classic", "simplified"):
+            run(kind, 64, 5000, 128, 256, seed=0, ncheck=1, reps=3)
+            run(kind, 256, 4000, 128, 256, seed=1, ragged=True, ncheck=1, reps=3)
+            run(kind, 256, 3000, 100, 256, seed=2, ragged=True, ncheck=1, reps=3)
