@@ -109,7 +109,10 @@ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 // renormalisation period inside a block and the number of lanes the lattice front can cross in one period
 template <int BLK, int NL>
 struct Cad {
-  static constexpr int RN = (BLK % 4 == 0) ? 4 : 3;
+#ifndef CTC_F6_RN12
+#define CTC_F6_RN12 4
+#endif
+  static constexpr int RN = (BLK % 4 == 0) ? CTC_F6_RN12 : 3;
   static constexpr int NG = BLK / RN;            // exponent groups of the rows of one block
   static constexpr int LV = (RN + NL - 1) / NL;  // adoption levels: lanes the lattice front can cross in one period
   static_assert(BLK % RN == 0, "block length must be a multiple of the renormalisation period");
