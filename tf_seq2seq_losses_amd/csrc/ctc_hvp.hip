@@ -60,7 +60,15 @@ __global__ __launch_bounds__(256) void temit_kernel(Problem p, Layout L, const f
   if (p.wrt == 0) {  // u = J v = v - (softmax . v): direction in log-probability space (tools.py:37-39 differentiated)
     const float *x = p.logits + row * (long)V;
     const float mx = emis[row * (long)L.ERS + L.UP + 1], l2s = emis[row * (long)L.ERS + L.UP + 2];
-    for (int k = lane; k < V; k += 64) sv += fexp2((x[k] - mx) * LOG2E - l2s) * v[k];
+    if (((V & 3) | (int)((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(v)) & 15)) == 0) {  // 16 bytes per lane
+      for (int k = lane * 4; k < V; k += 256) {
+        const float4 xv = *reinterpret_cast<const float4 *>(x + k), vv = *reinterpret_cast<const float4 *>(v + k);
+        sv += (fexp2((xv.x - mx) * LOG2E - l2s) * vv.x + fexp2((xv.y - mx) * LOG2E - l2s) * vv.y) +
+              (fexp2((xv.z - mx) * LOG2E - l2s) * vv.z + fexp2((xv.w - mx) * LOG2E - l2s) * vv.w);
+      }
+    } else {
+      for (int k = lane; k < V; k += 64) sv += fexp2((x[k] - mx) * LOG2E - l2s) * v[k];
+    }
     sv = wave_sum(sv);
   }
   float *drow = demis + row * (long)L.ERS;
@@ -385,9 +393,20 @@ __global__ __launch_bounds__(256) void hvp_out_kernel(Problem p, Layout L, const
     const float *x = p.logits + row * (long)V, *v = vec + row * (long)V;
     const float mx = emis[row * (long)L.ERS + UP + 1], l2s = emis[row * (long)L.ERS + UP + 2];
     const float sv = demis[row * (long)L.ERS + UP + 1];
-    for (int k = lane; k < V; k += 64) {
-      const float s = fexp2((x[k] - mx) * LOG2E - l2s);
-      __builtin_nontemporal_store(-bin[k] + s * (v[k] - sv), o + k);  // H_lp u + (diag(s) - s s^T) v
+    if (((V & 3) | (int)((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(o)) & 15)) == 0) {
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      for (int k = lane * 4; k < V; k += 256) {  // 16 bytes per lane in and out
+        const float4 xv = *reinterpret_cast<const float4 *>(x + k), vv = *reinterpret_cast<const float4 *>(v + k);
+        const float4 bq = *reinterpret_cast<const float4 *>(bin + k);
+        const v4f r = {-bq.x + fexp2((xv.x - mx) * LOG2E - l2s) * (vv.x - sv), -bq.y + fexp2((xv.y - mx) * LOG2E - l2s) * (vv.y - sv),
+                       -bq.z + fexp2((xv.z - mx) * LOG2E - l2s) * (vv.z - sv), -bq.w + fexp2((xv.w - mx) * LOG2E - l2s) * (vv.w - sv)};
+        __builtin_nontemporal_store(r, reinterpret_cast<v4f *>(o + k));
+      }
+    } else {
+      for (int k = lane; k < V; k += 64) {
+        const float s = fexp2((x[k] - mx) * LOG2E - l2s);
+        __builtin_nontemporal_store(-bin[k] + s * (v[k] - sv), o + k);  // H_lp u + (diag(s) - s s^T) v
+      }
     }
   } else {
     for (int k = lane; k < V; k += 64) __builtin_nontemporal_store(-bin[k], o + k);
