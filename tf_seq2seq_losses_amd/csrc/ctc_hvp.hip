@@ -450,6 +450,7 @@ hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec
   float *dalpha = reinterpret_cast<float *>(ex + H.off_dalpha);
   float *dbeta = reinterpret_cast<float *>(ex + H.off_dbeta);
   float *dlogp = reinterpret_cast<float *>(ex + H.off_dlogp);
+  // (four rows per wavefront, as emit4_kernel does, was tried here and lost: 195 against 172 us at the north-star shape)
   hipLaunchKernelGGL(temit_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, L, emis, vec, demis);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

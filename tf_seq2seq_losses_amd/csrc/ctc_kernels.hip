@@ -13,6 +13,7 @@
 //                 base_loss.py:262-298, 420-468 and TF's autodiff of tools.py:37-39).
 #include "ctc_common.h"
 #include "ctc_amd.h"
+#include "ctc_swap_reduce.h"
 
 namespace ctc {
 
@@ -102,6 +103,93 @@ __global__ __launch_bounds__(256) void emit_kernel(Problem p, Layout L, float *_
     erow[L.UP + 1] = mx;
     erow[L.UP + 2] = log2sum;
     erow[L.UP + 3] = 0.f;
+  }
+}
+
+// Small vocabularies (V <= 512, float32, 16-byte aligned rows): FOUR consecutive frames of one utterance per wavefront.
+// One wavefront per row spent most of its time waiting -- a row is one or two 16-byte loads per lane, then two dependent
+// gathers (label -> token -> logit) per label position.  Here the rows' loads go out together, the four maxima and the four
+// sums are reduced through one register each (ctc_swap_reduce.h), and the label tokens are fetched once for all four rows.
+__global__ __launch_bounds__(256) void emit4_kernel(Problem p, Layout L, float *__restrict__ emis) {
+  using namespace ctc::fused;
+  const int lane = threadIdx.x & 63;
+  const int nq = (p.T + 3) / 4;
+  const long id = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (id >= (long)p.B * nq) return;
+  const int b = (int)(id / nq), t0 = 4 * (int)(id % nq);
+  const int len = clampi(p.logit_length[b], 0, p.T);
+  if (t0 >= len) return;  // padded frames are never read downstream
+  const int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  const int V = p.V;
+  const float *xb = p.logits + (long)b * p.xsb;
+  const float *xr[4];
+  bool on[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    on[r] = t0 + r < len;
+    xr[r] = xb + (long)(on[r] ? t0 + r : t0) * p.xst;  // (rows past the length re-read row t0: nothing of theirs is written)
+  }
+  float mx[4], l2s[4];
+  if (p.wrt == 0) {
+    float4 v[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int k = lane * 4 + 256 * c;
+        v[r][c] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (k < V) v[r][c] = *reinterpret_cast<const float4 *>(xr[r] + k);
+      }
+    float m[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      m[r] = fmaxf(fmaxf(fmaxf(v[r][0].x, v[r][0].y), fmaxf(v[r][0].z, v[r][0].w)), fmaxf(fmaxf(v[r][1].x, v[r][1].y), fmaxf(v[r][1].z, v[r][1].w)));
+    const float mall = swap_reduce<4, true>(m);
+    float s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float mm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mall), SwapLanes<4>::lane(r)));
+      mx[r] = (mm == -INFINITY) ? 0.f : mm;
+      s[r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        s[r] += (fexp2((v[r][c].x - mx[r]) * LOG2E) + fexp2((v[r][c].y - mx[r]) * LOG2E)) +
+                (fexp2((v[r][c].z - mx[r]) * LOG2E) + fexp2((v[r][c].w - mx[r]) * LOG2E));
+    }
+    const float sall = swap_reduce<4, false>(s);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) l2s[r] = flog2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(sall), SwapLanes<4>::lane(r))));  // -inf when the whole row is -inf
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mx[r] = 0.f; l2s[r] = 0.f; }
+  }
+  // log2 p(token k) = (x[k] - mx) * log2e - log2sum, gathered per label position (base_loss.py:328-344)
+  float *erow = emis + ((long)b * p.T + t0) * (long)L.ERS;
+  for (int i = lane; i < L.UP; i += 64) {
+    int tok = -1;
+    if (i < ll) tok = (i < p.label_stride) ? p.labels[(long)b * p.label_stride + i] : p.blank;
+    const bool ok = tok >= 0 && tok < V && tok != p.blank;  // (a label equal to the blank: impossible emission, see emit_kernel)
+    float g[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g[r] = ok ? xr[r][tok] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float e = ok ? fmaxf((g[r] - mx[r]) * LOG2E - l2s[r], NEG) : NEG;
+      if (!(e == e)) e = NEG;
+      if (on[r]) erow[(long)r * L.ERS + i] = e;
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float bl = NEG;
+      if (p.blank >= 0 && p.blank < V) bl = fmaxf((xr[r][p.blank] - mx[r]) * LOG2E - l2s[r], NEG);
+      if (!(bl == bl)) bl = NEG;
+      if (on[r]) {
+        float *e4 = erow + (long)r * L.ERS + L.UP;
+        e4[0] = bl; e4[1] = mx[r]; e4[2] = l2s[r]; e4[3] = 0.f;
+      }
+    }
   }
 }
 
@@ -715,7 +803,10 @@ hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *los
   double *logp = reinterpret_cast<double *>(ws + L.off_logp);
   const long rows = (long)p.B * p.T;
   if (rows > 0) {
-    hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, L, emis);
+    const bool four = p.V <= 512 && p.xdtype == 0 && (p.align_bits & 15) == 0 && ((p.V | p.xsb | p.xst) & 3) == 0;
+    const long waves = (long)p.B * ((p.T + 3) / 4);
+    if (four) hipLaunchKernelGGL(emit4_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, p, L, emis);
+    else hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, L, emis);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
