@@ -20,7 +20,10 @@ def _intact(buf, nbytes):
 @pytest.mark.parametrize("kind", [0, 1])
 @pytest.mark.parametrize("B,T,V,U,dtype", [(5, 37, 29, 11, "f32"), (3, 50, 256, 128, "f32"), (4, 41, 300, 40, "f32"),
                                              (2, 30, 1021, 17, "f32"), (3, 26, 64, 200, "f32"), (4, 33, 32, 9, "bf16"),
-                                             (300, 13, 8, 3, "f32"), (2, 40, 2048, 12, "f32")])
+                                             (300, 13, 8, 3, "f32"), (2, 40, 2048, 12, "f32"),
+                                             # long labels (eight per lane, 3-frame blocks), wide vocabulary with a half-full last pass
+                                             (2, 620, 256, 300, "f32"), (2, 70, 512, 512, "f32"), (2, 23, 4100, 9, "f32"),
+                                             (3, 31, 2560, 20, "f32")])
 def test_loss_grad_stays_inside_its_buffers(kind, B, T, V, U, dtype):
     from tf_seq2seq_losses_amd import _lib
     lib = _lib.load()
