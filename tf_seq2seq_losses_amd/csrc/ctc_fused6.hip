@@ -567,11 +567,7 @@ struct Rows {
     char *bb = reinterpret_cast<char *>(bins);
 #pragma unroll
     for (int j = 0; j < NL; ++j)  // (positions beyond label_length sit out: their adds would all hit the one pad slot and serialise)
-#ifdef CTC_F6_NOVALID
-      atomicAdd(reinterpret_cast<unsigned *>(bb + tokoff[j]), (unsigned)(qt[j] + 0.5f));
-#else
       if (valid[j]) atomicAdd(reinterpret_cast<unsigned *>(bb + tokoff[j]), (unsigned)(qt[j] + 0.5f));
-#endif
     wave_lds_fence();  // the bins read below were written by other lanes
     const float c1 = -dl * 9.31322574615478515625e-10f;
     const float c2 = dl * inv;
@@ -580,9 +576,6 @@ struct Rows {
       const uint4 pu = *reinterpret_cast<const uint4 *>(bins + 256 * q + lane * 4);
       const float4 pq = make_float4((float)pu.x + mb[4 * q] * qb, (float)pu.y + mb[4 * q + 1] * qb,
                                     (float)pu.z + mb[4 * q + 2] * qb, (float)pu.w + mb[4 * q + 3] * qb);
-#ifdef CTC_F6_NOSTORE  // experiment: no gradient traffic (results are wrong)
-      if (pq.x * c1 + c2 * ev[q].x == 123.456f)
-#endif
       io.store_g(t, q, make_float4(pq.x * c1 + c2 * ev[q].x, pq.y * c1 + c2 * ev[q].y, pq.z * c1 + c2 * ev[q].z, pq.w * c1 + c2 * ev[q].w));
     }
   }
@@ -647,9 +640,6 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL, VPL, XT> &S, Lds<KI
     int dd = d < nv ? d : nv - 1;
     int t = geo.frame(SIDE, g, dd < 0 ? 0 : dd);
     t = t < len ? t : len - 1;
-#ifdef CTC_F6_SAMEROW  // experiment: every phase-1 load hits the same (cached) row -- results are wrong
-    t = 0;
-#endif
     return t < 0 ? 0 : t;
   };
   constexpr int NQA = NQ > 0 ? NQ : 1;
@@ -728,11 +718,7 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL, VPL, XT> &S, Lds<KI
       }
       static_for<0, NQA>([&](auto Q) {
         constexpr int q = decltype(Q)::value;
-#ifdef CTC_F6_NT1
-        S.io.load_x_last(xb[r][q], fr(j + PFD, P0 + q));
-#else
         S.io.load_x(xb[r][q], fr(j + PFD, P0 + q));
-#endif
       });
       const bool mine = lane >= P0 && lane < P0 + NQ && lane < nv;
       float2 *dst = mine ? stats + geo.frame(SIDE, g, mine ? lane : 0) : sink;  // unconditional store: no branch
@@ -1008,10 +994,6 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
             tok[0] *= KS;
             p0 = S.cx * e.bl * r0;
           }
-#ifdef CTC_F6_NOPROD  // experiment: the main chain computes no posterior parts -- results are wrong
-          qal = 0.f; qsh = 0.f; p0 = 0.f;
-          for (int jj = 0; jj < NL; ++jj) tok[jj] = 0.f;
-#endif
           qsh = (lane == 0) ? qsh + p0 * K0 : qsh;  // the boundary state (uniform) rides in lane 0's scaled part
           float *srow = RR[d] + 2 * lane * NL;
           if constexpr (NL == 1) *reinterpret_cast<float2 *>(srow) = make_float2(tok[0], qsh);
@@ -1142,11 +1124,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
         read_E<NL, LD>(E[d], lane, e);
         S.step(e);
       };
-#ifdef CTC_F6_NOREC  // experiment: the recompute chain does not advance -- results are wrong
-      auto stpb = [&](auto D) __attribute__((always_inline)) { (void)eb; };
-#else
       auto stpb = [&](auto D) __attribute__((always_inline)) { S.step(eb[decltype(D)::value]); };
-#endif
       auto after = [&](bool more) __attribute__((always_inline)) {
         ++s;
         if (s % RN == 0 && more) {
@@ -1308,14 +1286,8 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         st_next = stats[fr(2, j + 1, lane)];
         // rows of the next block: their register set was freed by the G stage of the previous iteration, so the loads go out
         // first and have the whole iteration (not the part after this block's E stage) to arrive
-#ifndef CTC_F6_NOLOAD2  // (experiment: no second read of the logits -- results are wrong)
         static_for<0, FPH>([&](auto Q) { S.io.load_x(X[rn][decltype(Q)::value], fr(2, j + 1, h + NH * decltype(Q)::value)); });
-#endif
-#ifdef CTC_F6_NOE2  // experiment: no E stage in phase 2 (stale emission rows) -- results are wrong
-        if (false) {
-#else
         if (FAST || __builtin_expect(nv == BLK, 1)) {
-#endif
           static_for<0, FPH>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             const int d = h + NH * q;

@@ -196,32 +196,13 @@ struct Side {
       }
     }
   }
-  // the same row for the LAST time (phase 2 of the linear-domain kernel): non-temporal, so the line does not displace
-  // logits that still wait for their second read in the last-level cache
-  __device__ __forceinline__ void load_x_last(float4 (&xr)[VPL], int t) const {
-    if constexpr (XT == 0) {
-      typedef float v4f __attribute__((ext_vector_type(4)));
-      const float *row = xbase + (long)t * V + lane * 4;
-#pragma unroll
-      for (int q = 0; q < VPL; ++q) {
-        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(row + 256 * q));
-        xr[q] = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    } else {
-      load_x(xr, t);
-    }
-  }
   // one gradient row segment (4 values of this lane) in the output element type.  Non-temporal stores: the gradient is
   // written once and never read here; keeping it out of L2 leaves the cache to the logits, checkpoints and statistics
   // (measured -4.5 % kernel time; non-temporal LOADS of the logits cost +5 %).
   __device__ __forceinline__ static void nt_store4(float *p, float4 r) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     v4f v = {r.x, r.y, r.z, r.w};
-#ifdef CTC_GSTORE_PLAIN  // experiment: default cache policy for the gradient
-    *reinterpret_cast<v4f *>(p) = v;
-#else
     __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
-#endif
   }
   __device__ __forceinline__ void store_g(int t, int q, float4 r) const {
     if constexpr (XT == 0) {
