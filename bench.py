@@ -104,26 +104,128 @@ def cpu_baseline(kind, host, budget_s=15.0):
     return out
 
 
-def _events_ms(fn, steps, warmup):
-    """Mean device time of fn() over `steps` calls (HIP events on torch's current stream = the launch stream) and the wall
-    time per call of the same loop."""
+def _events_ms(fn, steps, warmup, dist=None, run=4):
+    """Mean device time of fn() over `steps` calls (HIP events on torch's current stream = the launch stream; one pair around
+    every run of `run` consecutive calls, see main) and the wall time per call of the same loop; `dist`, if a dict, receives
+    the distribution of the per-call times of the runs."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    steps = max(run, steps // run * run)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps // run)]
     t0 = time.perf_counter()
     for a, b in ev:
         a.record()
-        fn()
+        for _ in range(run):
+            fn()
         b.record()
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / steps
-    return sum(a.elapsed_time(b) for a, b in ev) / steps, wall * 1e3
+    ts = [a.elapsed_time(b) / run for a, b in ev]
+    if dist is not None:
+        dist.update(_dist([t * 1e3 for t in ts]))
+    return sum(ts) / len(ts), wall * 1e3
+
+
+def _dist(us):
+    """min / median / p90 / max of a list of per-launch times in microseconds"""
+    v = sorted(us)
+    return dict(n=len(v), min=round(v[0], 2), median=round(v[len(v) // 2], 2), p90=round(v[min(len(v) - 1, int(len(v) * 0.9))], 2),
+                max=round(v[-1], 2))
+
+
+def prewarm(fn, min_ms=100.0, max_calls=4000):
+    """Runs fn() until at least min_ms of device time has passed on the current stream (clocks, caches and the HBM power state
+    in their steady state whatever --warmup says); returns the number of calls made."""
+    n, spent = 0, 0.0
+    while spent < min_ms and n < max_calls:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(16):
+            fn()
+        b.record()
+        b.synchronize()
+        spent += a.elapsed_time(b)
+        n += 16
+    return n
+
+
+def box_probe(lib, device):
+    """One-off probe of the box the bench runs on: a 1 GiB float4 copy (ctc_amd_probe_copy: 16 B per lane, non-temporal
+    stores), best and median of 8 -> GB/s of read + written bytes.  Lets a reader tell a slow box from a slow kernel."""
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=device).zero_()
+    dst = torch.empty(n, dtype=torch.uint8, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    ts = []
+    for i in range(10):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = lib.ctc_amd_probe_copy(dst.data_ptr(), src.data_ptr(), n, st)
+        b.record()
+        b.synchronize()
+        assert rc == 0
+        if i >= 2:
+            ts.append(a.elapsed_time(b))
+    ts.sort()
+    del src, dst
+    return dict(box_copy_GBps=round(2 * n / ts[len(ts) // 2] / 1e6, 1), box_copy_best_GBps=round(2 * n / ts[0] / 1e6, 1),
+                what="1 GiB device-to-device float4 copy, read + written bytes per second, median / best of 8")
+
+
+class EmulatedAllReduce:
+    """Stand-in for dist.all_reduce(buf, async_op=True) on ONE GPU: what ProcessGroupNCCL does around the collective -- its
+    own stream waits for the compute stream, runs the collective kernel, and work.wait() makes the compute stream wait for
+    that -- with a one-workgroup kernel of RCCL's footprint in place of the collective (512 threads, 4 KB of LDS, polling the
+    device clock for `us` microseconds: a two-number all-reduce over xGMI is latency-bound, ~10-20 us)."""
+
+    class _Work:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    def __init__(self, lib, device, us=12.0, threads=512, lds=4096):
+        self.lib, self.us, self.threads, self.lds = lib, us, threads, lds
+        self.side = torch.cuda.Stream(device=device)
+
+    def __call__(self, buf):
+        ready = torch.cuda.Event()
+        ready.record()                       # the pair of this step exists once the compute stream gets here
+        self.side.wait_event(ready)
+        rc = self.lib.ctc_amd_probe_spin(self.threads, self.lds, self.us, self.side.cuda_stream)
+        assert rc == 0
+        done = torch.cuda.Event()
+        done.record(self.side)
+        return EmulatedAllReduce._Work(done)
+
+
+def emulated_collective_table(lib, step_sum_factory, device, steps=120):
+    """Step time of the bench loop with no collective, and with the emulated one at pipeline depth 1 and 2 (VERDICT r02
+    item 5): does a kernel of RCCL's footprint run beside 256 workgroups that hold 159 000 of 163 840 bytes of LDS each?"""
+    from tf_seq2seq_losses_amd import dist as cdist
+    out = {}
+    for name, depth, emulate in (("no_collective", 1, False), ("emulated_depth1", 1, True), ("emulated_depth2", 2, True)):
+        step = step_sum_factory(depth + 2)
+        emu = EmulatedAllReduce(lib, device) if emulate else None
+        cdist.pipelined_steps(step, 20, reduced=True, depth=depth, all_reduce=emu)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        cdist.pipelined_steps(step, steps, reduced=True, depth=depth, all_reduce=emu)
+        b.record()
+        torch.cuda.synchronize()
+        out[name] = dict(wall_us_per_step=round((time.perf_counter() - t0) / steps * 1e6, 2), device_us_per_step=round(a.elapsed_time(b) / steps * 1e3, 2))
+    out["what"] = ("loss+gradient step (ctc_amd_loss_grad_sum) in dist.pipelined_steps on one GPU; emulated = a 512-thread, 4 KB-LDS kernel polling "
+                   "for 12 us on a second stream per step, ordered like RCCL's all-reduce (tf_seq2seq_losses_amd/dist.py)")
+    return out
 
 
 def _lossgrad_callable(lib, _lib, ops, kind, dev, B, T, U, V):
     prep = ops.Prepared(dev["labels"], dev["logits"], dev["label_length"], dev["logit_length"], 0, U=U)
-    ws = torch.empty(_lib.workspace_bytes(_lib.WS_LOSS_GRAD, kind, B, T, V, U), dtype=torch.uint8, device=prep.device)
+    ws = torch.empty(_lib.workspace_bytes(_lib.WS_LOSS_GRAD_LOGITS, kind, B, T, V, U), dtype=torch.uint8, device=prep.device)
     loss = torch.empty(B, dtype=torch.float32, device=prep.device)
     grad = torch.empty((B, T, V), dtype=torch.float32, device=prep.device)
     args_c = prep.common(kind, _lib.WRT_LOGITS) + (loss.data_ptr(), grad.data_ptr(), None, ws.data_ptr(), ws.numel())
@@ -134,6 +236,30 @@ def _lossgrad_callable(lib, _lib, ops, kind, dev, B, T, U, V):
             _lib.check(rc, "ctc_amd_loss_grad")
         return loss
     step.keep = (prep, ws, loss, grad)
+    return step
+
+
+def _sum_step_factory(lib, _lib, ops, device, rank, nbuf, B=256, T=1000, U=128, V=256):
+    """step() of the headline workload in its one-launch form with the in-launch loss sum, over `nbuf` rotating int64[2] buffers"""
+    host, dev = make_inputs(B, T, U, V, seed=rank, ragged=False, device=device)
+    prep = ops.Prepared(dev["labels"], dev["logits"], dev["label_length"], dev["logit_length"], 0, U=U)
+    ws = torch.empty(_lib.workspace_bytes(_lib.WS_LOSS_GRAD_LOGITS, 0, B, T, V, U), dtype=torch.uint8, device=device)
+    loss = torch.empty(B, dtype=torch.float32, device=device)
+    grad = torch.empty((B, T, V), dtype=torch.float32, device=device)
+    sums = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(nbuf)]
+    x = dev["logits"]
+    args = (0, _lib.WRT_LOGITS, x.data_ptr(), _lib.F32, x.stride(0), x.stride(1), prep.labels.data_ptr(), prep.stride,
+            prep.label_length.data_ptr(), prep.logit_length.data_ptr(), 0, B, T, V, U, loss.data_ptr(), grad.data_ptr(),
+            _lib.F32, grad.stride(0), grad.stride(1), None)
+    state = {"i": 0, "keep": (prep, ws, loss, grad, dev)}
+
+    def step():
+        k = state["i"] % nbuf
+        state["i"] += 1
+        rc = lib.ctc_amd_loss_grad_sum(*args, sums[k].data_ptr(), sums[(k + 1) % nbuf].data_ptr(), ws.data_ptr(), ws.numel(),
+                                       torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        return sums[k]
     return step
 
 
@@ -156,12 +282,13 @@ def secondary(device, rank):
     def lossgrad(name, kind_name, ragged, seed, B=B, T=T, U=U, V=V, steps=50):
         host, dev = make_inputs(B, T, U, V, seed=seed, ragged=ragged, device=device)
         step = _lossgrad_callable(lib, _lib, ops, ops.KINDS[kind_name], dev, B, T, U, V)
-        kms, wms = _events_ms(step, steps, 10)
+        d = {}
+        kms, wms = _events_ms(step, steps, 10, d)
         frames = int(host["logit_length"].sum())
         out[name] = dict(workload=f"{kind_name}_ctc_loss loss+grad B={B} T={T} U={U} V={V} fp32 {'ragged' if ragged else 'full-length'}",
                          value=B / (wms * 1e-3), unit="utterances/s", ms_per_step=wms,
                          pipeline=_lib.pipeline_name(ops.KINDS[kind_name], 0, B, T, V, U, True),
-                         roofline=_roof(frames * 2 * V * 4, kms, traffic=None))
+                         roofline=_roof(frames * 2 * V * 4, kms, traffic=None, kernel_us=d))
 
     lossgrad("config3_simplified", "simplified", False, rank)
     lossgrad("classic_ragged", "classic", True, 1)
@@ -184,7 +311,7 @@ def secondary(device, rank):
     # Hessian-vector product (second-order backward), north-star shape
     prep = ops.Prepared(dev["labels"], dev["logits"], dev["label_length"], dev["logit_length"], 0, U=U)
     vec = torch.randn((B, T, V), device=device, generator=torch.Generator(device=device).manual_seed(0))
-    kms, wms = _events_ms(lambda: ops.hvp(ops.KINDS["classic"], _lib.WRT_LOGITS, prep, vec), 10, 3)
+    kms, wms = _events_ms(lambda: ops.hvp(ops.KINDS["classic"], _lib.WRT_LOGITS, prep, vec), 12, 3)
     out["hvp"] = dict(workload=f"ctc_amd_hvp (Hessian-vector product, no [B,T,V,T,V] tensor) B={B} T={T} U={U} V={V}",
                       value=B / (wms * 1e-3), unit="utterances/s", ms_per_step=wms,
                       roofline=_roof(B * 3 * T * V * 4, kms, traffic=None, note="algorithmic bytes: logits + vector read, product written"))
@@ -203,11 +330,59 @@ def secondary(device, rank):
         rc = lib.ctc_amd_hessian(*prep.common(kindc, _lib.WRT_LOGITS), loss.data_ptr(), None, hess.data_ptr(), ws.data_ptr(), ws.numel(),
                                  torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "ctc_amd_hessian")
-    kms, wms = _events_ms(hstep, 5, 2)
+    d = {}
+    kms, wms = _events_ms(hstep, 8, 3, d, run=2)
     out["config5_hessian"] = dict(workload=f"classic_ctc_loss dense Hessian B={Bh} T={Th} U={Uh} V={Vh} fp32 (one ctc_amd_hessian call)",
                                   value=Bh / (wms * 1e-3), unit="utterances/s", ms_per_step=wms,
-                                  roofline=_roof(Bh * ((Th * Vh) ** 2 * 4 + Th * Vh * 4), kms, traffic=None))
+                                  roofline=_roof(Bh * ((Th * Vh) ** 2 * 4 + Th * Vh * 4), kms, traffic=None, kernel_us=d))
+    del hess, ws
+    out["reference_table"] = reference_table(device)
+    out["emulated_collective"] = emulated_collective_table(lib, lambda nbuf: _sum_step_factory(lib, _lib, ops, device, rank, nbuf), device)
+    # the headline workload once more, after everything else: tells a warm-up transient of a cold process from a slow box
+    lossgrad("classic_full_length_again", "classic", False, rank, steps=100)
     return out
+
+
+def reference_table(device):
+    """The reference's only published experiment (README.md:16-24, tests/benchmark.py:41-43,110-162,182-237) on this GPU:
+    batch 256, 32 tokens, 255 frames, ragged lengths in the distribution of tests/common.py:77-94 with the label tensor as
+    wide as T, forward and forward + gradient through the public Python functions (wall clock per call incl. Python, as the
+    reference measures), next to torch's own CTC on the same GPU.  SURVEY.md section 8 (f4)."""
+    import tf_seq2seq_losses_amd as ctc
+    B, T, V = 256, 255, 32
+    rng = np.random.default_rng(0)
+    logits = torch.from_numpy(rng.standard_normal((B, T, V), dtype=np.float32)).to(device)
+    tl = torch.from_numpy(rng.integers(T // 2, T, B, dtype=np.int32)).to(device)
+    ll_h = rng.integers(T // 4, T // 2, B, dtype=np.int32)
+    ll = torch.from_numpy(ll_h).to(device)
+    labels = torch.from_numpy(rng.integers(1, V, (B, T), dtype=np.int32)).to(device)
+
+    def torch_ctc(labels, x, ll, tl, blank=0):
+        lp = torch.log_softmax(x, dim=2).transpose(0, 1)
+        return torch.nn.functional.ctc_loss(lp, labels.long(), tl.long(), ll.long(), blank=blank, reduction="none")
+
+    def wall(fn, steps=30, warmup=5):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+    rows = {}
+    for name, fn in (("torch.nn.functional.ctc_loss", torch_ctc), ("classic_ctc_loss", ctc.classic_ctc_loss), ("simple_ctc_loss", ctc.simple_ctc_loss)):
+        def forward():
+            with torch.no_grad():
+                return fn(labels, logits, ll, tl, 0)
+
+        def gradient():
+            x = logits.detach().requires_grad_(True)
+            loss = fn(labels, x, ll, tl, 0)
+            return torch.autograd.grad(loss.sum(), x)[0]
+        rows[name] = dict(forward_ms=round(wall(forward), 4), forward_gradient_ms=round(wall(gradient), 4))
+    return dict(workload=f"reference README table: B={B} T={T} V={V}, ragged lengths, label tensor {T} wide (labels <= {int(ll_h.max())}), "
+                         "wall clock per call incl. Python, 30 calls after 5", rows=rows)
 
 
 def main():
@@ -226,6 +401,13 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (simplified, ragged, drop-in autograd, HVP, Hessian)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="element type of logits and gradient (producer format)")
     ap.add_argument("--time-major", action="store_true", help="logits stored [T,B,V] (producer format), passed as a strided view")
+    ap.add_argument("--pipeline-depth", type=int, default=1,
+                    help="steps the all-reduce of sum(loss) may lag behind the loss kernel (dist.pipelined_steps depth)")
+    ap.add_argument("--emulate-collective", action="store_true",
+                    help="N = 1 only: stand in for RCCL's all-reduce with a kernel of its footprint on a second stream (ctc_amd_probe_spin), "
+                         "ordered as the real one is")
+    ap.add_argument("--prewarm-ms", type=float, default=100.0,
+                    help="after the --warmup steps, keep launching the timed kernel until this much device time has passed (untimed; 0 = off)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse ranks that share one GPU)")
     args = ap.parse_args()
@@ -251,6 +433,7 @@ def main():
 
     if args.hessian:
         args.B, args.T, args.U, args.V = 32, 200, 32, 64
+        NBUF = 3
     B, T, U, V = args.B, args.T, args.U, args.V
     kind = ops.KINDS[args.kind]
     host, dev = make_inputs(B, T, U, V, seed=rank, ragged=args.ragged, device=device)
@@ -271,13 +454,14 @@ def main():
         alg_bytes = B * ((T * V) ** 2 * 4 + T * V * 4)
     else:
         # outputs and workspace are allocated once (the C ABI never allocates); one step = one ctc_amd_loss_grad call
-        ws = torch.empty(_lib.workspace_bytes(_lib.WS_LOSS_GRAD, kind, B, T, V, U), dtype=torch.uint8, device=device)
+        ws = torch.empty(_lib.workspace_bytes(_lib.WS_LOSS_GRAD_LOGITS, kind, B, T, V, U), dtype=torch.uint8, device=device)
         loss = torch.empty(B, dtype=torch.float32, device=device)
         grad = torch.empty((B, T, V), dtype=torch.float32, device=device)
         lib = _lib.load()
         # sum(loss) and the finite count of a step, accumulated by the loss kernel itself in fixed point: three int64[2] buffers
         # in rotation (step i fills i mod 3 and clears (i+1) mod 3; the collective of step i-1 may still be reading (i-1) mod 3)
-        sums = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(3)]
+        NBUF = args.pipeline_depth + 2
+        sums = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(NBUF)]
         native = args.dtype != "f32" or args.time_major
         if native:  # producer formats through ctc_amd_loss_grad_ex: no conversion pass anywhere
             xf = dev["logits"].to(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
@@ -297,7 +481,7 @@ def main():
 
             def step_sum(k):  # the same call + sum(loss) accumulated inside the launch (ctc_amd_loss_grad_sum)
                 a = ex_args
-                rc = lib.ctc_amd_loss_grad_sum(*a[:21], sums[k].data_ptr(), sums[(k + 1) % 3].data_ptr(), a[21], a[22],
+                rc = lib.ctc_amd_loss_grad_sum(*a[:21], sums[k].data_ptr(), sums[(k + 1) % NBUF].data_ptr(), a[21], a[22],
                                                torch.cuda.current_stream().cuda_stream)
                 if rc:
                     _lib.check(rc, "ctc_amd_loss_grad_sum")
@@ -316,7 +500,7 @@ def main():
                         _lib.F32, grad.stride(0), grad.stride(1), None)
 
             def step_sum(k):  # the same call + sum(loss) accumulated inside the launch (ctc_amd_loss_grad_sum)
-                rc = lib.ctc_amd_loss_grad_sum(*sum_args, sums[k].data_ptr(), sums[(k + 1) % 3].data_ptr(), ws.data_ptr(), ws.numel(),
+                rc = lib.ctc_amd_loss_grad_sum(*sum_args, sums[k].data_ptr(), sums[(k + 1) % NBUF].data_ptr(), ws.data_ptr(), ws.numel(),
                                                torch.cuda.current_stream().cuda_stream)
                 if rc:
                     _lib.check(rc, "ctc_amd_loss_grad_sum")
@@ -333,25 +517,30 @@ def main():
 
     for _ in range(args.warmup):
         full_step()
+    # ... and, whatever --warmup says, at least 100 ms of the timed launch: a cold process ran its first ~25 launches 10 %
+    # slow (r02: driver 174 us at --warmup 5 against 152-157 us at --warmup 20 on the same commit)
+    extra_warm = prewarm(step, args.prewarm_ms) if args.prewarm_ms > 0 else 0
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    # the dominant kernel is timed live inside the timed region: one HIP event pair per launch on the launch stream
-    # (torch's current stream), averaged over the K steps -- the number the roofline fraction is priced on
-    # (every 4th launch carries the pair, so that event recording does not perturb the step time it is part of)
+    # the dominant kernel is timed live inside the timed region: HIP event pairs on the launch stream (torch's current stream),
+    # each around a run of KEV consecutive launches (a pair around every single launch adds the 5-8 us the stream needs to
+    # process the two event packets to the kernel it brackets and serialises its dispatch behind them: 158 against 150 us
+    # here) -- launch duration = bracketed time / KEV, averaged over the K steps; the number the roofline fraction is priced on
     KEV = 4
-    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((args.steps + KEV - 1) // KEV)]
+    ngrp = (args.steps + KEV - 1) // KEV
+    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(ngrp)]
     in_kernel_sum = not args.hessian
 
     def timed_step():
         i = timed_step.i
         if i % KEV == 0:
             kev[i // KEV][0].record()
-        loss_t = step_sum(i % 3) if in_kernel_sum else step()
-        if i % KEV == 0:
+        loss_t = step_sum(i % NBUF) if in_kernel_sum else step()
+        if i % KEV == KEV - 1 or i == args.steps - 1:
             kev[i // KEV][1].record()
         timed_step.i += 1
         return loss_t
@@ -361,7 +550,8 @@ def main():
     # per step: ONE launch (loss + gradient + the [sum(loss), #finite] pair, ctc_amd_loss_grad_sum) + (N > 1) one asynchronous
     # all-reduce of the pair; the Hessian workload keeps the separate ctc_amd_reduce_loss launch
     seen = []
-    cdist.pipelined_steps(timed_step, args.steps, reduced=in_kernel_sum,
+    emu = EmulatedAllReduce(lib, device) if (args.emulate_collective and world == 1) else None
+    cdist.pipelined_steps(timed_step, args.steps, reduced=in_kernel_sum, depth=args.pipeline_depth, all_reduce=emu,
                           consume=(lambda i, pair: seen.append(pair) if i == args.steps - 1 else None) if in_kernel_sum else None)
     ev1.record()
     torch.cuda.synchronize()
@@ -379,7 +569,19 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
-    kernel_ms = sum(a.elapsed_time(b) for a, b in kev) / len(kev)
+    kernel_ts = [a.elapsed_time(b) / min(KEV, args.steps - KEV * g) for g, (a, b) in enumerate(kev)]  # per launch, by group
+    kernel_ms = sum(a.elapsed_time(b) for a, b in kev) / args.steps
+    # after the timed region: the same launch 100 more times with an event pair around each, for the per-launch distribution
+    post = []
+    if not args.hessian:
+        for _ in range(100):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            step()
+            b.record()
+            post.append((a, b))
+        torch.cuda.synchronize()
+        post = [a.elapsed_time(b) * 1e3 for a, b in post]
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
@@ -414,11 +616,17 @@ def main():
             "dtype": "f32" if args.dtype == "f32" else "f32 arithmetic, bf16 logits/gradient in HBM", "data": "synthetic",
             "config": {"workload": f"{args.kind}_ctc_loss {'hessian' if args.hessian else 'loss+grad'} B={B} T={T} U={U} V={V} {'fp32' if args.dtype == 'f32' else 'bf16 logits/gradient, fp32 arithmetic'} per GPU"
                                    + (" ragged" if args.ragged else " full-length") + (" time-major [T,B,V]" if args.time_major else ""),
-                       "global_batch": B * world, "parallelism": f"batch-sharded x{world}, all-reduce of sum(loss)"},
+                       "global_batch": B * world,
+                       "parallelism": f"batch-sharded x{world}, all-reduce of sum(loss) {args.pipeline_depth} step(s) behind"
+                                      + (" (EMULATED on one GPU: ctc_amd_probe_spin on a second stream)" if emu is not None else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src if not args.hessian else None,
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": alg_bytes,
-                         "kernel_ms_per_launch": kernel_ms, "device_ms_per_step_incl_reduction": dev_ms_per_step},
+                         "kernel_ms_per_launch": kernel_ms, "device_ms_per_step_incl_reduction": dev_ms_per_step,
+                         "kernel_us_in_timed_region": dict(_dist([t * 1e3 for t in kernel_ts]), what=f"per launch, event pairs around runs of {KEV} launches"),
+                         "kernel_us_after_timed_region": dict(_dist(post), what="100 more launches, an event pair around EACH (adds the event packets' own time)") if post else None},
+            "warmup_effective": args.warmup + extra_warm,
+            "box": box_probe(lib, device) if world == 1 else None,
         }
         if not args.no_cpu_baseline and not args.hessian and world == 1:  # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(args.kind, host)

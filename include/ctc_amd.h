@@ -13,7 +13,8 @@
  *     synchronisation, and is therefore capturable into a hipGraph.
  *   - The caller owns every buffer, including the workspace (size from ctc_amd_workspace_bytes).
  *     Outputs are fully overwritten.  The library keeps no global state besides a thread-local
- *     error string; calls are re-entrant for distinct (stream, workspace) pairs.
+ *     error string and the test-only tier override of ctc_amd_debug_override (never set by the product path);
+ *     calls are re-entrant for distinct (stream, workspace) pairs.
  *   - Layouts are dense row-major: logits[B][T][V] float32, labels[B][label_stride] int32,
  *     label_length[B], logit_length[B] int32, loss[B], grad[B][T][V], hess[B][T][V][T][V] float32.
  *   - `U` is a static upper bound on label_length (the reference uses the dynamic max(label_length),
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CTC_AMD_ABI_VERSION 2
+#define CTC_AMD_ABI_VERSION 3
 
 /* lattice variant */
 #define CTC_AMD_CLASSIC 0    /* classic_ctc_loss.py:33-70   (collapse repeats, then drop blanks)   */
@@ -57,8 +58,9 @@ extern "C" {
  *   U <= CTC_AMD_MAX_U          label positions (16 per lane of one wavefront)
  *   V <= CTC_AMD_MAX_V          tokens for loss / gradient / alpha-beta (one 64 KB LDS token row per wavefront)
  *   V <= CTC_AMD_MAX_V_HESSIAN  tokens for ctc_amd_hessian / ctc_amd_hvp (V + 4 floats of LDS per wavefront)
- * Vector (16-byte / 8-byte) row accesses are used when V, the strides AND the base pointers are aligned; any other
- * alignment runs element-wise paths with identical results. */
+ * ctc_amd_loss_grad* / ctc_amd_grad_resume / ctc_amd_alpha_beta: vector (16-byte / 8-byte) row accesses are used when V, the
+ * strides AND the base pointers are aligned; any other alignment runs element-wise paths with identical results.
+ * ctc_amd_hessian / ctc_amd_hvp require 16-byte aligned tensor pointers (CTC_AMD_EINVAL otherwise). */
 #define CTC_AMD_MAX_U 1024
 #define CTC_AMD_MAX_V 16384
 #define CTC_AMD_MAX_V_HESSIAN 16380
@@ -68,6 +70,10 @@ extern "C" {
 #define CTC_AMD_WS_ALPHA_BETA 1
 #define CTC_AMD_WS_HESSIAN 2
 #define CTC_AMD_WS_HVP 3
+/* ctc_amd_loss_grad* / ctc_amd_grad_resume with wrt == CTC_AMD_WRT_LOGITS and float32 (or 8-byte aligned bfloat16) tensors:
+ * the workspace of the pipeline such a call selects -- checkpoint rows only when that is a fused tier (64 MB instead of
+ * 680 MB at B=256 T=1000 U=128).  CTC_AMD_WS_LOSS_GRAD stays valid for every call (log-probability input, any format). */
+#define CTC_AMD_WS_LOSS_GRAD_LOGITS 4
 
 /* element types of the producer formats (ctc_amd_loss_grad_ex) */
 #define CTC_AMD_F32 0
@@ -92,6 +98,14 @@ const char *ctc_amd_pipeline_name(int kind, int wrt, int B, int T, int V, int U,
 int ctc_amd_debug_override(const char *key /*host*/, const char *value /*host*/);
 
 /*
+ * Diagnostic (tests/tools/soak.py, the parity tests): byte offset, inside the workspace of a float32 logits call of these
+ * shapes (CTC_AMD_WS_LOSS_GRAD_LOGITS layout), of the int32[B] flag words the linear-domain fused kernel leaves -- 0 = the
+ * utterance was computed in the linear domain, != 0 = it was redone by the log-domain roles (bits D1..D6).
+ * Returns CTC_AMD_EINVAL when that call would not run the "fused6" pipeline.
+ */
+int ctc_amd_debug_flags_offset(int kind, int B, int T, int V, int U, size_t *out_offset /*host*/);
+
+/*
  * out2[0] = sum of the finite entries of loss[B], out2[1] = their number (as float): the two scalars a data-parallel
  * training loop all-reduces (tf.reduce_sum / reduce_mean of the loss: README.md:62, tests/benchmark.py:199), in one launch.
  * Asynchronous on `stream` like the compute entry points.
@@ -107,6 +121,19 @@ int ctc_amd_reduce_loss(const float *loss, int B, float *out2, void *stream);
  */
 int ctc_amd_check_labels(const int32_t *labels, int label_stride, const int32_t *label_length, int blank_index,
                          int B, int V, int U, void *stream);
+
+/*
+ * Measurement aid (bench.py's box probe): copies `bytes` (a multiple of 16) from src to dst with the access shape of the
+ * kernels' row traffic (16 bytes per lane, non-temporal stores), asynchronously on `stream`.  Not part of the hot path.
+ */
+int ctc_amd_probe_copy(void *dst, const void *src, size_t bytes, void *stream);
+
+/*
+ * Measurement aid (bench.py --emulate-collective): ONE workgroup of `threads` threads holding `lds_bytes` of LDS that polls
+ * the device clock for `microseconds` and exits -- the footprint of a latency-bound RCCL all-reduce kernel, to measure on
+ * one GPU whether such a kernel runs beside the loss kernel or waits for its tail.  Asynchronous on `stream`.
+ */
+int ctc_amd_probe_spin(int threads, int lds_bytes, float microseconds, void *stream);
 
 /* Bytes of device workspace the call selected by `what` needs for these shapes. */
 int ctc_amd_workspace_bytes(int what, int kind, int B, int T, int V, int U, size_t *out_bytes /*host*/);

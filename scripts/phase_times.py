@@ -11,5 +11,5 @@ prep = ops.Prepared(dev["labels"], dev["logits"], dev["label_length"], dev["logi
 kind = 1 if os.environ.get("F6_KINDNAME", "classic") == "simplified" else 0
 for _ in range(40):
     loss, ws = ops.loss_forward(kind, _lib.WRT_LOGITS, prep)
-    g = ops.grad_resume(kind, _lib.WRT_LOGITS, prep, loss, ws)
+    g = ops.grad_resume(kind, _lib.WRT_LOGITS, prep, ws)
 torch.cuda.synchronize()

@@ -46,6 +46,14 @@ def test_workspace_bytes_and_argument_errors(lib):
     # emissions [B,T,UP+4] + alpha, beta [B,T+1,2*UP+4] + logp
     assert n >= 256 * 1000 * 132 * 4 + 2 * 256 * 1001 * 264 * 4
     assert _lib.workspace_bytes(_lib.WS_HESSIAN, _lib.SIMPLIFIED, 2, 5, 3, 4) > _lib.workspace_bytes(_lib.WS_LOSS_GRAD, _lib.SIMPLIFIED, 2, 5, 3, 4)
+    # the workspace of a logits call is the selected pipeline's own: checkpoint rows only on the fused tiers (<= 64 MB at the
+    # north star), the full lattice rows where the three-kernel pipeline runs (long labels, BPE-sized vocabularies)
+    small = _lib.workspace_bytes(_lib.WS_LOSS_GRAD_LOGITS, _lib.CLASSIC, 256, 1000, 256, 128)
+    assert small <= 64 << 20 < n
+    assert _lib.workspace_bytes(_lib.WS_LOSS_GRAD_LOGITS, 0, 4, 100, 256, 1000) == _lib.workspace_bytes(_lib.WS_LOSS_GRAD, 0, 4, 100, 256, 1000)
+    assert _lib.flags_offset(0, 256, 1000, 256, 128) < small
+    with pytest.raises(ValueError):
+        _lib.flags_offset(0, 4, 100, 256, 1000)  # three-kernel pipeline: no flags
     with pytest.raises(ValueError):
         _lib.workspace_bytes(7, 0, 1, 1, 1, 1)
     with pytest.raises(ValueError):

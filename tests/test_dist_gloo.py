@@ -84,6 +84,21 @@ def _loop_worker(rank, world, port, out):
     assert sorted(got) == list(range(7))
     for i, pr in enumerate(pairs):
         assert abs(got[i][0] / 1048576.0 - float(pr[0])) < 1e-3 and got[i][1] == int(pr[1])
+    # pipeline depth 2 (bench.py --pipeline-depth 2): the pair of step i is waited for after step i+2 has been launched;
+    # depth + 2 = 4 buffers in rotation, each consumed before it is recycled
+    calls["n"] = 0
+    bufs4 = [torch.zeros(2, dtype=torch.int64) for _ in range(4)]
+    got2 = {}
+
+    def step_reduced2():
+        i = calls["n"]
+        loss = step()
+        fin = torch.isfinite(loss)
+        bufs4[(i + 1) % 4].zero_()
+        bufs4[i % 4] += torch.stack([torch.round(loss[fin].double() * 1048576.0).sum().long(), fin.sum()])
+        return bufs4[i % 4]
+    assert cdist.pipelined_steps(step_reduced2, 7, reduced=True, depth=2, consume=lambda i, pair: got2.__setitem__(i, pair.tolist())) == []
+    assert got2 == got
     out[rank] = [p.tolist() for p in pairs]
     dist.destroy_process_group()
 

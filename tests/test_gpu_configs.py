@@ -46,6 +46,36 @@ def test_config5_full_batch_hessian(kind, kernel):
         _lib.debug_override("hessian", "")
 
 
+def _golden_slabs():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config5_hessian_slabs.npz"))
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+@pytest.mark.parametrize("kernel", ["pair", "slab"])
+def test_config5_logprob_space_hessian_entries(kind, kernel):
+    """loss_data.hessian (base_loss.py:186-260, derivatives w.r.t. log-probabilities) at the full T=200 U=32 V=64 of
+    configs[4] for utterances 0 and 13, entry by entry against the float64 gamma-oracle's slabs, 1e-4."""
+    import tf_seq2seq_losses_amd as ctc
+    from tf_seq2seq_losses_amd import _lib
+    B, T, U, V = 32, 200, 32, 64
+    logits, labels, ll, tl = _inputs(B, T, U, V, 0)
+    pick = [0, 13]
+    lp = torch.log_softmax(_t(logits[pick]).double(), dim=2).float()
+    cls = ctc.ClassicCtcLossData if kind == "classic" else ctc.SimplifiedCtcLossData
+    gold = _golden_slabs()
+    _lib.debug_override("hessian", "slab" if kernel == "slab" else "")
+    try:
+        h = cls(_t(labels[pick]), lp, _t(ll[pick]), _t(tl[pick]), 0).hessian
+    finally:
+        _lib.debug_override("hessian", "")
+    for i, b in enumerate(pick):
+        idx = gold[f"u{b}/index"]
+        want = gold[f"u{b}/{kind}/logprobs"]
+        got = torch.stack([h[i, int(t1), int(k1)] for t1, k1 in idx]).cpu().numpy()
+        assert np.abs(got - want).max() < TOL, (b, np.abs(got - want).max())
+
+
 def _config5_body(kind):
     from tf_seq2seq_losses_amd import ops, _lib
     B, T, U, V = 32, 200, 32, 64
@@ -68,6 +98,15 @@ def _config5_body(kind):
         n = int(tl[b])
         if n < T:
             assert h[b, n:].abs().max().item() == 0 and h[b, :, :, n:].abs().max().item() == 0
+    # entry by entry against the float64 gamma-oracle at FULL size: 20 slabs H[b, t1, k1, :, :] of utterances 0 and 13
+    # (tests/golden/config5_hessian_slabs.npz, written by tests/golden/make_config5_slabs.py from oracle/ctc_oracle.py)
+    gold = _golden_slabs()
+    for b in (0, 13):
+        idx = gold[f"u{b}/index"]
+        want = gold[f"u{b}/{kind}/logits"]
+        got = torch.stack([h[b, int(t1), int(k1)] for t1, k1 in idx]).cpu().numpy()
+        assert np.abs(got - want).max() < TOL, (b, np.abs(got - want).max())
+        assert abs(float(loss[b]) - float(gold[f"u{b}/{kind}/loss"][0])) < TOL * float(gold[f"u{b}/{kind}/loss"][0])
     # the two triangles are generated independently (forward / backward propagation): float32 rounding of T = 200 recursions
     assert worst_sym < 1e-4, worst_sym
     assert worst_gauge < 1e-4, worst_gauge

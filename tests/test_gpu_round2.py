@@ -52,12 +52,15 @@ def test_loss_then_resume_equals_one_call(kind, pipeline, B, T, U, V):
     _lib.debug_override("pipeline", pipeline)
     try:
         loss1, grad1 = ops.loss_grad(k, _lib.WRT_LOGITS, p, True, d_loss=w)
-        loss2, ws = ops.loss_forward(k, _lib.WRT_LOGITS, p)
-        grad2 = ops.grad_resume(k, _lib.WRT_LOGITS, p, loss2, ws, d_loss=w)
-        grad3 = ops.grad_resume(k, _lib.WRT_LOGITS, p, loss2, ws, d_loss=w)   # the workspace survives a resume: backward twice
+        loss2, ws = ops.loss_forward(k, _lib.WRT_LOGITS, p, keep_always=True)  # (ctc_amd_grad_resume behind every pipeline)
+        grad2 = ops.grad_resume(k, _lib.WRT_LOGITS, p, ws, d_loss=w)
+        grad3 = ops.grad_resume(k, _lib.WRT_LOGITS, p, ws, d_loss=w)   # the workspace survives a resume: backward twice
     finally:
         _lib.debug_override("pipeline", "")
-    assert torch.equal(loss1, loss2)
+    if pipeline == "fused2":  # needs a gradient: its loss-only call is the three-kernel pipeline's (another summation order),
+        assert torch.allclose(loss1, loss2, rtol=1e-6, atol=0)  # and the gradient call no longer rewrites the caller's loss
+    else:
+        assert torch.equal(loss1, loss2)
     assert torch.equal(grad1, grad2) and torch.equal(grad2, grad3)
     rl, rg = C.loss_grad(kind, labels, logits, ll, tl, 0)
     fin = np.isfinite(rl)
@@ -66,15 +69,9 @@ def test_loss_then_resume_equals_one_call(kind, pipeline, B, T, U, V):
 
 
 def _flags(ws, kind, B, T, V, U):
-    """per-utterance flags the linear-domain kernel left in the workspace (Layout::off_flags of csrc/ctc_common.h)"""
-    al = lambda x: (x + 255) & ~255
-    nl = 1
-    while nl * 64 < U:
-        nl *= 2
-    UP = nl * 64; ERS = UP + 4; SRS = (2 * UP if kind == 0 else UP) + 8
-    o = al(B * T * ERS * 4); o = al(o + B * (T + 1) * SRS * 4); o = al(o + B * (T + 1) * SRS * 4)
-    o = al(o + B * 8); o = al(o + B * 2 * 1024); o = al(o + B * 4)
-    o = al(o + B * 2 * ((T + 2) // 3 + 3) * 64 * 4)
+    """per-utterance flags the linear-domain kernel left in the workspace (ctc_amd_debug_flags_offset)"""
+    from tf_seq2seq_losses_amd import _lib
+    o = _lib.flags_offset(kind, B, T, V, U)
     return ws[o:o + 4 * B].view(torch.int32).cpu().numpy()
 
 
@@ -117,7 +114,7 @@ def test_long_labels_on_the_linear_kernel_at_full_length(kind, T, U):
     assert np.abs(grad.cpu().numpy() - rg).max() < 1e-5
     assert (np.abs(loss.cpu().numpy() - rl) / rl).max() < 1e-6
     loss2, ws2 = ops.loss_forward(k, _lib.WRT_LOGITS, p)
-    grad2 = ops.grad_resume(k, _lib.WRT_LOGITS, p, loss2, ws2)
+    grad2 = ops.grad_resume(k, _lib.WRT_LOGITS, p, ws2)
     assert torch.equal(loss, loss2) and torch.equal(grad, grad2)
 
 

@@ -1,0 +1,187 @@
+"""Round-3 parity tests (need a real MI355X: `pytest -m gpu`):
+
+* the reference's own benchmark experiment (tests/benchmark.py:41-43,110-162 with the inputs of tests/common.py:53-104:
+  batch 256, 32 tokens, 255 frames, ragged lengths, label tensor as wide as the frames) through the public functions
+  against the float64 C oracle -- SURVEY.md section 8 (f4);
+* the label-length bound: a label tensor padded to T selects the tier of the labels inside it (hint, host copy, cached
+  device-side maximum), with identical results;
+* the two-call forward/backward never writes to the loss tensor it returned, also when an utterance is flagged late;
+* the workspace of a logits call is the pipeline's own (checkpoint rows only on the fused tiers);
+* unaligned base pointers: alpha/beta run element-wise, Hessian / HVP refuse them.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as C
+from oracle import ctc_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _t(a):
+    return torch.as_tensor(np.asarray(a)).to(_dev())
+
+
+def _reference_benchmark_inputs(B=256, T=255, V=32, seed=0):
+    """tests/common.py:72-94 of the reference: logits N(0,1); logit_length ~ U{T/2..T-1}; label_length ~ U{T/4..T/2-1};
+    labels uniform over the non-blank tokens in a tensor T wide."""
+    rng = np.random.default_rng(seed)
+    logits = rng.standard_normal((B, T, V), dtype=np.float32)
+    tl = rng.integers(T // 2, T, B, dtype=np.int32)
+    ll = rng.integers(T // 4, T // 2, B, dtype=np.int32)
+    labels = rng.integers(1, V, (B, T), dtype=np.int32)
+    return labels, logits, ll, tl
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_reference_benchmark_shape_against_the_oracle(kind):
+    import tf_seq2seq_losses_amd as ctc
+    from tf_seq2seq_losses_amd import ops, _lib
+    labels, logits, ll, tl = _reference_benchmark_inputs()
+    fn = ctc.classic_ctc_loss if kind == "classic" else ctc.simple_ctc_loss
+    x = _t(logits).requires_grad_(True)
+    loss = fn(_t(labels), x, _t(ll), _t(tl), 0)
+    w = torch.where(torch.isfinite(loss), loss, torch.zeros_like(loss))
+    (g,) = torch.autograd.grad(w.sum(), x)
+    rl, rg = C.loss_grad(kind, labels, logits, ll, tl, 0)
+    fin = np.isfinite(rl)
+    got = loss.detach().cpu().numpy()
+    assert np.array_equal(np.isfinite(got), fin)
+    assert (np.abs(got[fin] - rl[fin]) / np.maximum(1.0, np.abs(rl[fin]))).max() < TOL
+    gg = g.cpu().numpy()
+    assert np.abs(gg[fin] - rg[fin]).max() < TOL
+    assert not gg[~fin].any()  # infeasible samples: zero gradient (classic_ctc_loss.py:50-52)
+    for b in range(0, 256, 37):  # frames beyond logit_length: exact zeros (base_loss.py:291-296)
+        assert not gg[b, tl[b]:].any()
+    # the label tensor is 255 wide, the labels inside at most 126: the tier of 128 positions runs (two per lane)
+    p = ops.Prepared(_t(labels), _t(logits), _t(ll), _t(tl), 0)
+    assert p.U == int(ll.max()) <= 128 and _lib.pipeline_name(ops.KINDS[kind], 0, p.B, p.T, p.V, p.U, True) == "fused6"
+
+
+def test_label_length_bound_sources_agree():
+    """Hint, host copy of label_length and the cached device-side maximum select the same tier and give the same bits as the
+    width of the label tensor (any U >= max(label_length) is exact: the extra lattice states stay empty)."""
+    import tf_seq2seq_losses_amd as ctc
+    from tf_seq2seq_losses_amd import ops
+    labels, logits, ll, tl = _reference_benchmark_inputs(B=8, T=300, V=40, seed=3)
+    x = _t(logits)
+    wide = ops.Prepared(_t(labels), x, _t(ll), _t(tl), 0, U=300)           # the reference-free static bound: the width
+    assert wide.U == 300
+    dev_ll = _t(ll)
+    cached = ops.Prepared(_t(labels), x, dev_ll, _t(tl), 0)                 # device-side maximum, fetched once
+    assert cached.U == int(ll.max())
+    assert (dev_ll.data_ptr(), dev_ll._version, dev_ll.numel(), dev_ll.device) in ops._MAXLEN_CACHE
+    hinted = ops.Prepared(_t(labels), x, dev_ll, _t(tl), 0, host_max_label_length=200)
+    assert hinted.U == 200
+    ref = ops.loss_grad(0, 0, wide, True)
+    for p in (cached, hinted):
+        got = ops.loss_grad(0, 0, p, True)
+        assert torch.allclose(ref[0], got[0], rtol=1e-6, atol=0) and (ref[1] - got[1]).abs().max() < 1e-6
+    # public functions: keyword hint, and a host copy of label_length (NumPy) -- no device max needed
+    a = ctc.classic_ctc_loss(_t(labels), x, dev_ll, _t(tl), 0, max_label_length=int(ll.max()))
+    b = ctc.classic_ctc_loss(labels, x, ll, tl, 0)
+    assert torch.equal(a, b)
+    rl, _ = C.loss_grad("classic", labels, logits, ll, tl, 0, want_grad=False)
+    assert (np.abs(a.cpu().numpy() - rl) / np.abs(rl)).max() < TOL
+    # a bound below the true maximum is the caller's error and shows: those samples come out infeasible (ctc_amd.h)
+    low = ctc.classic_ctc_loss(_t(labels), x, dev_ll, _t(tl), 0, max_label_length=int(ll.max()) - 1)
+    assert torch.isinf(low[int(np.argmax(ll))])
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_backward_never_writes_the_returned_loss(kind):
+    """Two-call forward/backward on the fused tier: sharp logits flag utterances (some only in the second half: D5 / D6), the
+    log-domain roles redo them during backward -- into a scratch buffer, not into the tensor the user holds."""
+    import tf_seq2seq_losses_amd as ctc
+    rng = np.random.default_rng(11)
+    B, T, U, V = 6, 600, 40, 64
+    logits = (rng.standard_normal((B, T, V)) * np.array([1, 1, 3, 3, 6, 6])[:, None, None]).astype(np.float32)
+    labels = rng.integers(1, V, (B, U)).astype(np.int32)
+    ll, tl = np.full(B, U, np.int32), np.full(B, T, np.int32)
+    fn = ctc.classic_ctc_loss if kind == "classic" else ctc.simplified_ctc_loss
+    x = _t(logits).requires_grad_(True)
+    loss = fn(_t(labels), x, _t(ll), _t(tl), 0)
+    before = loss.detach().clone()
+    ver = loss._version
+    (g,) = torch.autograd.grad(loss.sum(), x)
+    torch.cuda.synchronize()
+    assert torch.equal(before, loss.detach()) and loss._version == ver
+    rl, rg = C.loss_grad(kind, labels, logits, ll, tl, 0)
+    assert (np.abs(before.cpu().numpy() - rl) / np.abs(rl)).max() < TOL
+    assert np.abs(g.cpu().numpy() - rg).max() < 2e-3  # (utterances redone in the log domain: that kernel's accuracy at T = 600)
+    assert np.abs(g.cpu().numpy()[:2] - rg[:2]).max() < 1e-5  # benign ones: the linear kernel's
+
+
+def test_autograd_keeps_only_the_checkpoint_workspace():
+    """What classic_ctc_loss saves for backward at the north-star shape of one utterance batch is the fused tier's own
+    workspace (checkpoint rows, statistics, flags), not the 2.6x-of-the-logits layout of the three-kernel pipeline; pipelines
+    without a two-call form save nothing but the input."""
+    import tf_seq2seq_losses_amd as ctc
+    from tf_seq2seq_losses_amd import _lib
+    B, T, U, V = 16, 1000, 128, 256
+    rng = np.random.default_rng(0)
+    x = _t(rng.standard_normal((B, T, V), dtype=np.float32)).requires_grad_(True)
+    labels = _t(rng.integers(1, V, (B, U), dtype=np.int32))
+    ll, tl = _t(np.full(B, U, np.int32)), _t(np.full(B, T, np.int32))
+    loss = ctc.classic_ctc_loss(labels, x, ll, tl, 0)
+    saved = [t for t in loss.grad_fn.saved_tensors if t is not None]
+    extra = sum(t.numel() * t.element_size() for t in saved if t.data_ptr() != x.data_ptr())
+    assert extra == _lib.workspace_bytes(_lib.WS_LOSS_GRAD_LOGITS, 0, B, T, V, U) < B * T * V * 4 // 2
+    # BPE-sized vocabulary: three-kernel pipeline, nothing kept
+    xw = _t(rng.standard_normal((2, 50, 2048), dtype=np.float32)).requires_grad_(True)
+    lw = ctc.classic_ctc_loss(labels[:2, :10], xw, _t(np.full(2, 10, np.int32)), _t(np.full(2, 50, np.int32)), 0)
+    assert all(t.data_ptr() == xw.data_ptr() for t in lw.grad_fn.saved_tensors if t is not None)
+    (gw,) = torch.autograd.grad(lw.sum(), xw)
+    assert torch.isfinite(gw).all()
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_unaligned_base_pointers_on_the_other_entry_points(kind):
+    """ctc_amd_alpha_beta reads logits at a base that is only 4-byte aligned through the element-wise path (same values as
+    the aligned call); ctc_amd_hessian / ctc_amd_hvp state 16-byte alignment as a requirement and refuse anything else."""
+    from tf_seq2seq_losses_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    B, T, V, U = 3, 20, 24, 6
+    rng = np.random.default_rng(5)
+    flat = torch.from_numpy(rng.standard_normal(B * T * V + 4).astype(np.float32)).to(dev)
+    x_un = flat[1:1 + B * T * V]           # base 4 bytes past a 16-byte boundary
+    x_al = x_un.clone()
+    assert x_un.data_ptr() % 16 == 4 and x_al.data_ptr() % 16 == 0
+    labels = torch.from_numpy(rng.integers(1, V, (B, U)).astype(np.int32)).to(dev)
+    ll = torch.full((B,), U, dtype=torch.int32, device=dev)
+    tl = torch.full((B,), T, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    n = _lib.workspace_bytes(_lib.WS_ALPHA_BETA, kind, B, T, V, U)
+    ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    S = 2 if kind == 0 else 1
+    outs = []
+    for x in (x_al, x_un):
+        loss = torch.empty(B, device=dev)
+        a = torch.empty(B * (T + 1) * (U + 1) * S, device=dev)
+        b = torch.empty_like(a)
+        rc = lib.ctc_amd_alpha_beta(kind, 0, x.data_ptr(), labels.data_ptr(), U, ll.data_ptr(), tl.data_ptr(), 0, B, T, V, U,
+                                    loss.data_ptr(), a.data_ptr(), b.data_ptr(), ws.data_ptr(), n, st)
+        assert rc == 0, lib.ctc_amd_last_error()
+        outs.append((loss, a, b))
+    torch.cuda.synchronize()
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.equal(u, v)
+    nh = _lib.workspace_bytes(_lib.WS_HVP, kind, B, T, V, U)
+    wsh = torch.empty(nh, dtype=torch.uint8, device=dev)
+    vec = torch.zeros(B * T * V, device=dev)
+    out = torch.empty(B * T * V, device=dev)
+    loss = torch.empty(B, device=dev)
+    rc = lib.ctc_amd_hvp(kind, 0, x_un.data_ptr(), labels.data_ptr(), U, ll.data_ptr(), tl.data_ptr(), 0, B, T, V, U,
+                         vec.data_ptr(), loss.data_ptr(), None, out.data_ptr(), wsh.data_ptr(), nh, st)
+    assert rc == _lib.EINVAL and b"aligned" in lib.ctc_amd_last_error()
+    rc = lib.ctc_amd_hvp(kind, 0, x_al.data_ptr(), labels.data_ptr(), U, ll.data_ptr(), tl.data_ptr(), 0, B, T, V, U,
+                         vec.data_ptr(), loss.data_ptr(), None, out.data_ptr(), wsh.data_ptr(), nh, st)
+    assert rc == 0, lib.ctc_amd_last_error()
+    torch.cuda.synchronize()

@@ -12,10 +12,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTC_AMD_LIB", os.path.join(_HERE, "libctc_amd.so"))  # override: kernel experiments only
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 CLASSIC, SIMPLIFIED = 0, 1
 WRT_LOGITS, WRT_LOGPROBS = 0, 1
-WS_LOSS_GRAD, WS_ALPHA_BETA, WS_HESSIAN, WS_HVP = 0, 1, 2, 3
+WS_LOSS_GRAD, WS_ALPHA_BETA, WS_HESSIAN, WS_HVP, WS_LOSS_GRAD_LOGITS = 0, 1, 2, 3, 4
 OK, EINVAL, EWORKSPACE, EHIP, ELABEL = 0, -1, -2, -3, -4
 F32, BF16 = 0, 1
 
@@ -32,7 +32,10 @@ SIGNATURES = {
     "ctc_amd_last_error": (ctypes.c_char_p, []),
     "ctc_amd_pipeline_name": (ctypes.c_char_p, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "ctc_amd_debug_override": (_c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    "ctc_amd_debug_flags_offset": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_size_t)]),
     "ctc_amd_reduce_loss": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),
+    "ctc_amd_probe_copy": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "ctc_amd_probe_spin": (_c_int, [_c_int, _c_int, ctypes.c_float, _c_void_p]),
     "ctc_amd_check_labels": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "ctc_amd_workspace_bytes": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_size_t)]),
     "ctc_amd_loss_grad": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
@@ -57,6 +60,7 @@ SIGNATURES = {
 }
 
 _lib = None
+override_generation = 0  # bumped by debug_override: cached pipeline names / workspace sizes of ops.py are keyed on it
 
 
 class CtcAmdError(RuntimeError):
@@ -101,7 +105,16 @@ def pipeline_name(kind: int, wrt: int, B: int, T: int, V: int, U: int, want_grad
 def debug_override(key: str, value: str = "") -> None:
     """Diagnostic (parity tests, benchmarks): force a lower kernel tier ("pipeline": "v1" | "fused2" | "fused5") or the
     general Hessian kernel ("hessian": "slab"); the empty string restores the default.  Process-wide."""
+    global override_generation
     check(load().ctc_amd_debug_override(key.encode(), value.encode()), "ctc_amd_debug_override")
+    override_generation += 1
+
+
+def flags_offset(kind: int, B: int, T: int, V: int, U: int) -> int:
+    """Diagnostic: where the linear-domain kernel's per-utterance flag words sit in a logits call's workspace."""
+    out = _c_size_t(0)
+    check(load().ctc_amd_debug_flags_offset(kind, B, T, V, U, ctypes.byref(out)), "ctc_amd_debug_flags_offset")
+    return int(out.value)
 
 
 def workspace_bytes(what: int, kind: int, B: int, T: int, V: int, U: int) -> int:

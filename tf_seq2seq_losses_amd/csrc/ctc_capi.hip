@@ -72,6 +72,8 @@ int g_force_pipeline = 0;      // 0 = best eligible tier, 1 = v1, 2 = fused2, 5 
 int g_force_hessian_slab = 0;  // 1 = the general one-slab-per-wavefront Hessian kernel also for short labels
 hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec, float *out, hipStream_t st);
 hipError_t run_reduce_loss(const float *loss, int B, float *out, hipStream_t st);
+hipError_t run_probe_copy(void *dst, const void *src, size_t bytes, hipStream_t st);
+hipError_t run_probe_spin(int threads, int lds_bytes, float us, hipStream_t st);
 hipError_t run_check_labels(const int32_t *labels, int label_stride, const int32_t *label_length, int blank, int B, int V, int U,
                             int *bad, hipStream_t st);
 }  // namespace ctc
@@ -113,10 +115,15 @@ ctc::Problem make_problem(int kind, int wrt, const float *logits, const int32_t 
   p.logits = logits; p.labels = labels; p.label_length = label_length; p.logit_length = logit_length;
   p.label_stride = label_stride; p.blank = blank; p.B = B; p.T = T; p.V = V; p.U = U; p.kind = kind; p.wrt = wrt;
   p.xsb = (long)T * V; p.xst = V; p.gsb = (long)T * V; p.gst = V; p.xdtype = 0; p.gdtype = 0;  // contiguous float32
+  p.align_bits = (int)(reinterpret_cast<uintptr_t>(logits) & 15);  // (entry points OR in the tensors they write)
   return p;
 }
 
 int hip_fail(hipError_t e, const char *where) { return fail(CTC_AMD_EHIP, "%s: %s", where, hipGetErrorString(e)); }
+
+int low_bits(const void *a, const void *b = nullptr, const void *c = nullptr, const void *d = nullptr) {
+  return (int)((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(d)) & 15);
+}
 
 }  // namespace
 
@@ -139,6 +146,13 @@ static const char *select_pipeline(const ctc::Problem &p, const ctc::Layout &L, 
   if (!want_grad) return "v1";
   if (ctc::fused_eligible(p, L)) return "fused2";
   return "v1";
+}
+
+// The fused tiers keep one checkpoint row per block and 8 bytes of statistics per frame: their layout is the compact one
+// (ctc_common.h Layout::ck_blk); every other pipeline needs full lattice rows.
+static ctc::Layout layout_for(const ctc::Problem &p, const char *pl) {
+  const bool compact = pl[0] == 'f' && (pl[5] == '5' || pl[5] == '6');
+  return ctc::make_layout(p.kind, p.B, p.T, p.U, 0, compact ? ctc::fused_blk(ctc::nl_for(p.U), p.V) : 0);
 }
 
 int ctc_amd_debug_override(const char *key, const char *value) {
@@ -164,10 +178,35 @@ const char *ctc_amd_pipeline_name(int kind, int wrt, int B, int T, int V, int U,
   return select_pipeline(p, L, want_grad != 0);
 }
 
+int ctc_amd_debug_flags_offset(int kind, int B, int T, int V, int U, size_t *out_offset) {
+  if (!out_offset) return fail(CTC_AMD_EINVAL, "out_offset is null");
+  if ((kind != 0 && kind != 1) || B < 0 || T < 0 || V <= 0 || U < 0 || U > MAX_U) return fail(CTC_AMD_EINVAL, "bad shape");
+  ctc::Problem p = make_problem(kind, CTC_AMD_WRT_LOGITS, nullptr, nullptr, 0, nullptr, nullptr, 0, B, T, V, U);
+  const char *pl = select_pipeline(p, ctc::make_layout(kind, B, T, U, 0), true);
+  if (strcmp(pl, "fused6")) return fail(CTC_AMD_EINVAL, "these shapes run the %s pipeline, which keeps no flags", pl);
+  *out_offset = layout_for(p, pl).off_flags;
+  return CTC_AMD_OK;
+}
+
 int ctc_amd_reduce_loss(const float *loss, int B, float *out2, void *stream) {
   if (B < 0 || !out2 || (B > 0 && !loss)) return fail(CTC_AMD_EINVAL, "bad arguments");
   hipError_t e = ctc::run_reduce_loss(loss, B, out2, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return hip_fail(e, "reduce launch");
+  return CTC_AMD_OK;
+}
+
+int ctc_amd_probe_copy(void *dst, const void *src, size_t bytes, void *stream) {
+  if (!dst || !src || (bytes & 15) || low_bits(dst, src) != 0) return fail(CTC_AMD_EINVAL, "probe copy needs 16-byte aligned pointers and size");
+  hipError_t e = ctc::run_probe_copy(dst, src, bytes, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail(e, "probe copy launch");
+  return CTC_AMD_OK;
+}
+
+int ctc_amd_probe_spin(int threads, int lds_bytes, float microseconds, void *stream) {
+  if (threads < 64 || threads > 1024 || (threads & 63) || lds_bytes < 0 || lds_bytes > 65536 || !(microseconds >= 0.f) || microseconds > 1000.f)
+    return fail(CTC_AMD_EINVAL, "probe spin: threads in 64..1024 (multiple of 64), lds_bytes <= 65536, microseconds <= 1000");
+  hipError_t e = ctc::run_probe_spin(threads, lds_bytes, microseconds, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail(e, "probe spin launch");
   return CTC_AMD_OK;
 }
 
@@ -195,6 +234,13 @@ int ctc_amd_workspace_bytes(int what, int kind, int B, int T, int V, int U, size
   if (kind != 0 && kind != 1) return fail(CTC_AMD_EINVAL, "bad kind %d", kind);
   if (B < 0 || T < 0 || V <= 0 || U < 0 || U > MAX_U) return fail(CTC_AMD_EINVAL, "bad shape B=%d T=%d V=%d U=%d", B, T, V, U);
   size_t extra = 0;
+  if (what == CTC_AMD_WS_LOSS_GRAD_LOGITS) {
+    // the pipeline a float32 / aligned bfloat16 logits call of this shape selects; its own (smaller) layout when that is a fused tier
+    ctc::Layout L0 = ctc::make_layout(kind, B, T, U, 0);
+    ctc::Problem p = make_problem(kind, CTC_AMD_WRT_LOGITS, nullptr, nullptr, 0, nullptr, nullptr, 0, B, T, V, U);
+    *out_bytes = layout_for(p, select_pipeline(p, L0, true)).total;
+    return CTC_AMD_OK;
+  }
   if (what == CTC_AMD_WS_HESSIAN) extra = ctc::hessian_extra_bytes(kind, B, T, V, U);
   else if (what == CTC_AMD_WS_HVP) extra = ctc::hvp_extra_bytes(kind, B, T, V, U);
   else if (what != CTC_AMD_WS_LOSS_GRAD && what != CTC_AMD_WS_ALPHA_BETA) return fail(CTC_AMD_EINVAL, "bad workspace selector %d", what);
@@ -206,12 +252,13 @@ static int loss_grad_impl(ctc::Problem p, float *loss, void *grad, const float *
                           size_t workspace_bytes, void *stream) {
   if (!loss) return fail(CTC_AMD_EINVAL, "null loss pointer");
   if (grad && p.V > MAX_V_GRAD) return fail(CTC_AMD_EINVAL, "V=%d exceeds the supported maximum %d for the gradient", p.V, MAX_V_GRAD);
-  ctc::Layout L = ctc::make_layout(p.kind, p.B, p.T, p.U, 0);
-  if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
   hipStream_t st = static_cast<hipStream_t>(stream);
   float *gradf = static_cast<float *>(grad);  // element-typed inside the kernels (Problem::gdtype)
-  p.align_bits = (int)((reinterpret_cast<uintptr_t>(p.logits) | reinterpret_cast<uintptr_t>(grad)) & 15);
-  const char *pl = select_pipeline(p, L, grad != nullptr);
+  p.align_bits = low_bits(p.logits, grad);
+  const char *pl = select_pipeline(p, ctc::make_layout(p.kind, p.B, p.T, p.U, 0), grad != nullptr);
+  const ctc::Layout L = layout_for(p, pl);
+  if (!workspace || workspace_bytes < L.total)
+    return fail(CTC_AMD_EWORKSPACE, "workspace too small for pipeline %s: %zu < %zu", pl, workspace_bytes, L.total);
   if (pl[0] == 'f') {
     char *wsb = static_cast<char *>(workspace);
     hipError_t ef = (pl[5] == '6') ? ctc::run_fused6(p, L, wsb, loss, d_loss, gradf, st)
@@ -317,6 +364,8 @@ int ctc_amd_grad_resume(int kind, int wrt, const void *logits, int logits_dtype,
   p.xsb = logits_stride_b; p.xst = logits_stride_t; p.xdtype = logits_dtype;
   p.gsb = grad_stride_b; p.gst = grad_stride_t; p.gdtype = grad_dtype;
   // only the linear-domain fused kernel keeps what the second half needs; every other pipeline computes loss and gradient anew
+  // (eligibility is decided on the same alignment bits the launch will see)
+  p.align_bits = low_bits(p.logits, grad);
   ctc::Layout L = ctc::make_layout(p.kind, p.B, p.T, p.U, 0);
   if (!strcmp(select_pipeline(p, L, true), "fused6")) p.resume = 1;
   return loss_grad_impl(p, loss, grad, d_loss, workspace, workspace_bytes, stream);
@@ -350,6 +399,7 @@ int ctc_amd_hessian(int kind, int wrt, const float *logits, const int32_t *label
   if (B == 0) return CTC_AMD_OK;
   if (!loss || !hess) return fail(CTC_AMD_EINVAL, "null output pointer");
   if (V > MAX_V_HESS) return fail(CTC_AMD_EINVAL, "V=%d exceeds the supported maximum %d of the Hessian", V, MAX_V_HESS);
+  if (low_bits(logits, grad, hess) != 0) return fail(CTC_AMD_EINVAL, "ctc_amd_hessian needs 16-byte aligned logits / grad / hess pointers");
   ctc::Layout L = ctc::make_layout(kind, B, T, U, ctc::hessian_extra_bytes(kind, B, T, V, U));
   if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
   ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
@@ -382,6 +432,7 @@ int ctc_amd_hvp(int kind, int wrt, const float *logits, const int32_t *labels, i
   if (B == 0) return CTC_AMD_OK;
   if (!loss || !out || (T > 0 && !vec)) return fail(CTC_AMD_EINVAL, "null vec/output pointer");
   if (V > MAX_V_HESS) return fail(CTC_AMD_EINVAL, "V=%d exceeds the supported maximum %d of the Hessian-vector product", V, MAX_V_HESS);
+  if (low_bits(logits, vec, grad, out) != 0) return fail(CTC_AMD_EINVAL, "ctc_amd_hvp needs 16-byte aligned logits / vec / grad / out pointers");
   ctc::Layout L = ctc::make_layout(kind, B, T, U, ctc::hvp_extra_bytes(kind, B, T, V, U));
   if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
   ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);

@@ -12,6 +12,30 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Product builds carry no experiment / diagnostic switch: every one of them is cleared here unless the build sets CTC_DIAG
+// (scripts/build_*variant.sh do).  (ctc_fused6.hip clears its own parameter macros the same way.)
+#ifndef CTC_DIAG
+#undef CTC_FUSED_STAMPS
+#undef CTC_F5_X
+#undef CTC_F5_Y
+#undef CTC_DBG_NO_E2
+#undef CTC_DBG_NO_G
+#undef CTC_HESS_STAMPS
+#undef CTC_HESS_DBG_NOSWEEP
+#undef CTC_HESS_DBG_NOFILL
+#undef CTC_HESS_DBG_NOSTORE
+#undef CTC_EXPERIMENT_NO_STORE
+#undef CTC_F6_STAMPS
+#undef CTC_F6_DEBUG
+#undef CTC_F6_DEBUG2
+#undef CTC_F6_SYNC
+#undef CTC_F6_ONLY
+#undef CTC_F6_X
+#undef CTC_F6_Y
+#undef CTC_F6_PFD
+#undef CTC_F6_RN12
+#endif
+
 namespace ctc {
 
 constexpr float NEG = -1.0e30f;
@@ -133,6 +157,11 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
 //   logp  [B] double       : log2 P(label | logits), -inf when infeasible
 struct Layout {
   int NL, UP, ERS, SRS;
+  // rows per utterance and direction in the alpha / beta regions, checkpoint slots per utterance and direction in the
+  // exponent region, and the block length of the compact layout (0: full layout, lattice row t lives at row index t;
+  // B > 0: only checkpoint rows exist, lattice time t lives at row index ceil(t / B) -- the fused tiers, which keep one
+  // row per block and 8 bytes of softmax statistics per frame in place of the emission rows)
+  int rows_b, nslot, ck_blk;
   size_t off_emis, off_alpha, off_beta, off_logp, off_dummy, off_perm, off_kexp, off_flags, off_meet, off_extra, total;
 };
 
@@ -142,24 +171,34 @@ inline int nl_for(int U) {
   return nl;
 }
 
-inline Layout make_layout(int kind, int B, int T, int U, size_t extra_bytes) {
+// frames per block of the checkpoint + recompute kernels (ctc_fused5.hip / ctc_fused6.hip launch tables)
+inline int fused_blk(int NL, int V) { return NL >= 8 ? 3 : (NL == 4 || V > 256) ? 6 : 12; }
+
+inline Layout make_layout(int kind, int B, int T, int U, size_t extra_bytes, int ck_blk = 0) {
   Layout L;
   L.NL = nl_for(U);
   L.UP = L.NL * WAVE;
   L.ERS = L.UP + 4;
   L.SRS = (kind == 0 ? 2 * L.UP : L.UP) + 8;
+  L.ck_blk = ck_blk;
+  L.rows_b = ck_blk > 0 ? (T + ck_blk - 1) / ck_blk + 3 : T + 1;
+  L.nslot = ck_blk > 0 ? L.rows_b : (T + 2) / 3 + 3;
   auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
   size_t o = 0;
-  L.off_emis = o;  o = al(o + (size_t)B * T * L.ERS * 4);
-  L.off_alpha = o; o = al(o + (size_t)B * (T + 1) * L.SRS * 4);
-  L.off_beta = o;  o = al(o + (size_t)B * (T + 1) * L.SRS * 4);
+  L.off_emis = o;  o = al(o + (ck_blk > 0 ? (size_t)B * T * 8 : (size_t)B * T * L.ERS * 4));
+  L.off_alpha = o; o = al(o + (size_t)B * L.rows_b * L.SRS * 4);
+  L.off_beta = o;  o = al(o + (size_t)B * L.rows_b * L.SRS * 4);
   L.off_logp = o;  o = al(o + (size_t)B * 8);
-  L.off_dummy = o; o = al(o + (size_t)B * 2 * 1024);  // (also: 16 B per wavefront of diagnostic stamps)  // per-wavefront sink for the pacing stores of the fused kernel
+  L.off_dummy = o; o = al(o + (size_t)B * 2 * 1024);  // per-wavefront sink for the pacing stores of the fused kernels (diagnostic builds: cycle stamps)
   L.off_perm = o;  o = al(o + (size_t)B * 4);  // longest-first order of the utterances (fused kernel, B > number of CUs)
-  // linear-domain fused kernel (ctc_fused6.hip): per-lane exponents of its checkpoint rows ([B][2][T/6 + 3][64] int32) and the
-  // per-utterance flags that send an utterance to the log-domain kernel
-  L.off_kexp = o;  o = al(o + (size_t)B * 2 * ((T + 2) / 3 + 3) * 64 * 4);
+  // linear-domain fused kernel (ctc_fused6.hip): per-lane exponents of its checkpoint rows ([B][2][nslot][64] int32) and the
+  // per-utterance flags that send an utterance to the log-domain roles
+  L.off_kexp = o;  o = al(o + (size_t)B * 2 * L.nslot * 64 * 4);
+#ifdef CTC_DIAG
   L.off_flags = o; o = al(o + (size_t)B * 4 + (size_t)B * 2048 * 4);  // (+ 8 KB per utterance for diagnostic builds)
+#else
+  L.off_flags = o; o = al(o + (size_t)B * 4);
+#endif
   L.off_meet = o;  o = al(o + (size_t)B * 8);  // per utterance: posterior scale (integer exponent, mantissa factor) from the meeting point
   L.off_extra = o; o = al(o + extra_bytes);
   L.total = o;

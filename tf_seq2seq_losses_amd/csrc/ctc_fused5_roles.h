@@ -343,8 +343,11 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
   const bool shape_ok = (ll <= p.U);
   if (!shape_ok) ll = 0;
   S.ll = ll;
-  S.own_rows = (DIR == 0 ? alpha_ws : beta_ws) + (long)b * (T + 1) * L.SRS;
-  S.oth_rows = (DIR == 0 ? beta_ws : alpha_ws) + (long)b * (T + 1) * L.SRS;
+  S.own_rows = (DIR == 0 ? alpha_ws : beta_ws) + (long)b * L.rows_b * L.SRS;
+  S.oth_rows = (DIR == 0 ? beta_ws : alpha_ws) + (long)b * L.rows_b * L.SRS;
+  // row index of lattice time t (a block boundary, the meeting point or `len`): t itself in the full layout, the block
+  // slot in the compact one (Layout::ck_blk)
+  auto rowidx = [&](int t) -> int { return L.ck_blk > 0 ? (t + BLK - 1) / BLK : t; };
   S.off = 0.0;
   init_labels<KIND, NL>(S, p, b, lane, ll);
   if constexpr (DIR == 0) {
@@ -371,7 +374,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
         const int nv = geo.nvof(g);
         const float(*E)[LD::ES] = lds.E[DIR][j % 3];
         // checkpoint: the state at the boundary this block starts from (alpha[BLK g] / beta[BLK g + nv])
-        S.spill(DIR == 0 ? BLK * g : BLK * g + nv, 0.f, 0.f);
+        S.spill(rowidx(DIR == 0 ? BLK * g : BLK * g + nv), 0.f, 0.f);
         if (nv == BLK) {
 #pragma unroll
           for (int d = 0; d < BLK; ++d) {
@@ -393,7 +396,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
       STAMP(st.end());
     }
   }
-  S.spill(geo.tm, 0.f, 0.f);  // alpha[tm] / beta[tm]: the meeting row
+  S.spill(rowidx(geo.tm), 0.f, 0.f);  // alpha[tm] / beta[tm]: the meeting row
 
   STAMP(st.phase1_done());
   // ================= meeting point =================
@@ -401,7 +404,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
   double dlogp;
   {
     SRow<KIND, NL> r;
-    load_srow<KIND, NL>(r, S.oth_rows + (long)geo.tm * L.SRS, lane, UP);
+    load_srow<KIND, NL>(r, S.oth_rows + (long)rowidx(geo.tm) * L.SRS, lane, UP);
     dlogp = S.meet(r);
     if (!shape_ok) dlogp = -INFINITY;
   }
@@ -483,7 +486,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
   S.cx = NEG;
   init_labels<KIND, NL>(S, p, b, lane, ll);
   // checkpoints of the direction this wave runs: written by the OTHER side's main chain in phase 1
-  const float *ck_rows = (RDIR == 0 ? alpha_ws : beta_ws) + (long)b * (T + 1) * L.SRS;
+  const float *ck_rows = (RDIR == 0 ? alpha_ws : beta_ws) + (long)b * L.rows_b * L.SRS;
   float *dump = lds.dump[2 + SIDE];
   STAMP(Stamps st; st.begin());
 
@@ -509,7 +512,8 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
     jj = jj < 0 ? 0 : jj;
     const int g = geo.absblock(2, SIDE, jj);
     int idx = (SIDE == 0) ? BLK * g + geo.nvof(g) : BLK * g;  // beta at the upper boundary / alpha at the lower one
-    return idx < 0 ? 0 : idx;
+    idx = idx < 0 ? 0 : idx;
+    return L.ck_blk > 0 ? (idx + BLK - 1) / BLK : idx;  // (row index: see run_main)
   };
   SRow<KIND, NL> ck_next;
   load_srow<KIND, NL>(ck_next, ck_rows + (long)ck_index(0) * L.SRS, lane, UP);

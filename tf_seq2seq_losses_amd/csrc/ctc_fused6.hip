@@ -46,6 +46,7 @@
 #error "compile with -DCTC_FUSED_KIND=0 (classic) or 1 (simplified)"
 #endif
 
+// (the CTC_F6_* switches below exist in CTC_DIAG builds only: ctc_common.h clears them otherwise)
 namespace ctc {
 namespace fused6 {
 
@@ -775,9 +776,9 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
   int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
   const bool shape_ok = (ll <= p.U);
   if (!shape_ok) ll = 0;
-  const int nslot = (T + 2) / 3 + 3;  // checkpoint slots per direction (sized for the shortest block length)
-  float *own_rows = (DIR == 0 ? alpha_ws : beta_ws) + (long)b * (T + 1) * SRS;
-  const float *oth_rows = (DIR == 0 ? beta_ws : alpha_ws) + (long)b * (T + 1) * SRS;
+  const int nslot = L.nslot;  // checkpoint slots per direction
+  float *own_rows = (DIR == 0 ? alpha_ws : beta_ws) + (long)b * L.rows_b * SRS;
+  const float *oth_rows = (DIR == 0 ? beta_ws : alpha_ws) + (long)b * L.rows_b * SRS;
   int *own_k = kexp_ws + ((long)b * 2 + DIR) * nslot * 64;
   const int *oth_k = kexp_ws + ((long)b * 2 + (1 - DIR)) * nslot * 64;
   S.init_labels(p, b, lane, ll);
@@ -1070,8 +1071,8 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
   const int T = p.T, UP = L.UP, SRS = L.SRS;
   int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
   if (ll > p.U) ll = 0;
-  const int nslot = (T + 2) / 3 + 3;
-  const float *ck_rows = (RDIR == 0 ? alpha_ws : beta_ws) + (long)b * (T + 1) * SRS;
+  const int nslot = L.nslot;
+  const float *ck_rows = (RDIR == 0 ? alpha_ws : beta_ws) + (long)b * L.rows_b * SRS;
   const int *ck_k = kexp_ws + ((long)b * 2 + RDIR) * nslot * 64;
   float *dump = lds.dump[2 + SIDE];
 

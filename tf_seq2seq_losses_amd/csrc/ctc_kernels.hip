@@ -938,4 +938,38 @@ hipError_t run_reduce_loss(const float *loss, int B, float *out, hipStream_t st)
   return hipGetLastError();
 }
 
+// box probe of bench.py (ctc_amd_probe_copy): a plain streaming copy, 16 bytes per lane, four loads in flight, non-temporal stores
+__global__ __launch_bounds__(512) void probe_copy_kernel(float4 *__restrict__ dst, const float4 *__restrict__ src, long n) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  long i = (long)blockIdx.x * 512 + threadIdx.x;
+  const long stride = (long)gridDim.x * 512;
+  auto put = [&](long k, float4 v) { v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(dst + k)); };
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    put(i, a); put(i + stride, b); put(i + 2 * stride, c); put(i + 3 * stride, d);
+  }
+  for (; i < n; i += stride) put(i, src[i]);
+}
+// stand-in for a latency-bound collective kernel (ctc_amd_probe_spin): one workgroup, some LDS, polls the 100 MHz device clock.
+// Every wavefront reaches the exit: the loop ends on elapsed time, with a hard bound on the trip count.
+__global__ void probe_spin_kernel(long long ticks, int lds_words) {
+  extern __shared__ int spin_lds[];
+  if (lds_words > 0) spin_lds[threadIdx.x % lds_words] = threadIdx.x;
+  const long long t0 = wall_clock64();
+  for (int it = 0; it < (1 << 22); ++it) {
+    if (wall_clock64() - t0 >= ticks) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (lds_words > 0 && spin_lds[0] == -12345) spin_lds[1] = 0;
+}
+hipError_t run_probe_spin(int threads, int lds_bytes, float us, hipStream_t st) {
+  hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(threads), (size_t)lds_bytes, st, (long long)(us * 100.0f), lds_bytes / 4);
+  return hipGetLastError();
+}
+hipError_t run_probe_copy(void *dst, const void *src, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  hipLaunchKernelGGL(probe_copy_kernel, dim3(2048), dim3(512), 0, st, static_cast<float4 *>(dst), static_cast<const float4 *>(src), (long)(bytes / 16));
+  return hipGetLastError();
+}
+
 }  // namespace ctc

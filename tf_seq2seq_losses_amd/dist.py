@@ -32,13 +32,15 @@ def reduce_loss_sum(local_loss: torch.Tensor, group=None) -> Tuple[torch.Tensor,
 
 
 def local_pair(local_loss: torch.Tensor) -> torch.Tensor:
-    """[sum of finite losses, number of finite losses] of this rank, float32[2] on the loss's device."""
+    """[sum of finite losses, number of finite losses] of this rank, float32[2] on the loss's device (float32 whatever the
+    dtype of the losses: the pair is what gets all-reduced)."""
     if local_loss.is_cuda:
-        from . import _lib
+        from . import _lib, ops
         buf = torch.empty(2, dtype=torch.float32, device=local_loss.device)
         x = local_loss if (local_loss.dtype == torch.float32 and local_loss.is_contiguous()) else local_loss.float().contiguous()
-        _lib.check(_lib.load().ctc_amd_reduce_loss(x.data_ptr() if x.numel() else None, x.numel(), buf.data_ptr(),
-                                                   torch.cuda.current_stream(x.device).cuda_stream), "ctc_amd_reduce_loss")
+        with ops._on_device(x.device):  # (the loss may live on a device that is not the current one)
+            _lib.check(_lib.load().ctc_amd_reduce_loss(x.data_ptr() if x.numel() else None, x.numel(), buf.data_ptr(),
+                                                       ops._stream(x.device)), "ctc_amd_reduce_loss")
         return buf
     finite = torch.isfinite(local_loss)  # CPU tensors (gloo tests): plain torch
     return torch.stack([torch.where(finite, local_loss, torch.zeros_like(local_loss)).sum(), finite.sum().to(local_loss.dtype)]).float()
@@ -55,38 +57,52 @@ def all_reduce_pair(local_loss: torch.Tensor, group=None, async_op: bool = False
 
 
 def pipelined_steps(step: Callable[[], torch.Tensor], steps: int, group=None, reduced: bool = False,
-                    consume: Callable[[int, torch.Tensor], None] = None):
+                    consume: Callable[[int, torch.Tensor], None] = None, depth: int = 1,
+                    all_reduce: Callable = None):
     """The data-parallel loop of bench.py: every step computes this rank's losses and issues the all-reduce of its
-    [sum, count] pair asynchronously; the pair of step i-1 is waited for after step i has been launched, so the
-    collective (two numbers, latency-bound) runs beside the next kernel.  Returns the list of reduced pairs, all
+    [sum, count] pair asynchronously; the pair of step i-depth is waited for after step i has been launched, so the
+    collective (two numbers, latency-bound) runs beside the next `depth` kernels.  Returns the list of reduced pairs, all
     complete on return.
 
     reduced=True: `step()` returns this rank's pair itself -- the int64[2] buffer ctc_amd_loss_grad_sum accumulated inside
     the loss kernel (fixed point: the all-reduced total has the same bits whatever the order) -- and no reduction launch is
-    left on the stream.  The caller cycles THREE such buffers: step i fills buffer i mod 3 and clears buffer (i+1) mod 3,
-    last used by step i-2, whose collective has been waited for by then.  `consume(i, pair)` is called once the pair of
-    step i is complete and before its buffer is recycled; in this mode the returned list is empty."""
-    out, pending = [], None
+    left on the stream.  The caller cycles depth + 2 such buffers: step i fills buffer i mod (depth + 2) and clears the next
+    one, last used by step i - depth - 1, whose collective has been waited for by then.  `consume(i, pair)` is called once the
+    pair of step i is complete and before its buffer is recycled; in this mode the returned list is empty.
+
+    all_reduce: stand-in for dist.all_reduce(buf, async_op=True) returning an object with .wait() (bench.py
+    --emulate-collective measures the loop on one GPU with a kernel of RCCL's footprint); default: the real collective when a
+    process group of more than one rank exists."""
+    assert depth >= 1
+    from collections import deque
+    out, pending = [], deque()
+
+    def issue(buf):
+        if all_reduce is not None:
+            return all_reduce(buf)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        return None
+
+    def retire():
+        buf, work, i = pending.popleft()
+        if work is not None:
+            work.wait()
+        if consume is not None:
+            consume(i, buf)
+
     for i in range(steps):
         if reduced:
-            buf, work = step(), None
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            buf = step()
         else:
-            buf, work = all_reduce_pair(step(), group=group, async_op=True)
-        if pending is not None:
-            if pending[1] is not None:
-                pending[1].wait()
-            if consume is not None:
-                consume(pending[2], pending[0])
-        pending = (buf, work, i)
+            buf = local_pair(step())
+        pending.append((buf, issue(buf), i))
+        if len(pending) > depth:
+            retire()
         if not reduced:
             out.append(buf)
-    if pending is not None:
-        if pending[1] is not None:
-            pending[1].wait()
-        if consume is not None:
-            consume(pending[2], pending[0])
+    while pending:
+        retire()
     return out
 
 

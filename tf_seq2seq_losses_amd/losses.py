@@ -19,7 +19,7 @@ All arithmetic is done by the HIP kernels behind the C ABI (include/ctc_amd.h); 
 from __future__ import annotations
 
 from functools import cached_property
-from typing import Union
+from typing import Optional, Union
 
 import numpy as np
 import torch
@@ -91,8 +91,7 @@ class _CtcGradient(torch.autograd.Function):
         ctx.kind, ctx.wrt, ctx.prep = kind, wrt, prep
         ctx.save_for_backward(x, d_loss)
         if pending is not None:  # the forward pass left its half of the work in a workspace: run the other half (one launch)
-            loss, ws = pending
-            return ops.grad_resume(kind, wrt, prep, loss, ws, d_loss=d_loss)
+            return ops.grad_resume(kind, wrt, prep, pending, d_loss=d_loss)
         return ops.loss_grad(kind, wrt, prep, True, d_loss=d_loss)[1]  # weighting inside the kernel
 
     @staticmethod
@@ -108,46 +107,62 @@ class _CtcGradient(torch.autograd.Function):
 
 
 class _CtcLoss(torch.autograd.Function):
-    """forward_fn (base_loss.py:140-155).  The forward pass runs the first half of the fused kernel (both lattice chains up
-    to their meeting point: the loss) and keeps its workspace; backward runs the second half from there with d_loss applied
-    inside the kernel -- together one loss+gradient call's work, no [B,T,V] tensor kept alive in between, no extra pass
-    over the gradient for the d_loss weights (ctc_amd_grad_resume)."""
+    """forward_fn (base_loss.py:140-155).  On the linear-domain fused tier the forward pass runs the first half of the kernel
+    (both lattice chains up to their meeting point: the loss) and keeps its checkpoint workspace (64 MB at the north-star
+    shape, saved with the graph and released with it); backward runs the second half from there with d_loss applied inside
+    the kernel -- together one loss+gradient call's work, no [B,T,V] tensor kept alive in between, no extra pass over the
+    gradient for the d_loss weights (ctc_amd_grad_resume).  Other pipelines keep nothing and compute the gradient in one
+    call during backward."""
 
     @staticmethod
     def forward(ctx, x, kind, wrt, prep):
         ctx.kind, ctx.wrt, ctx.prep = kind, wrt, prep
-        ctx.save_for_backward(x)
         if x.requires_grad:
             loss, ws = ops.loss_forward(kind, wrt, prep)
-            ctx.pending = (loss.detach(), ws)  # (an alias without autograd history: no reference cycle through ctx)
         else:
-            loss = ops.loss_grad(kind, wrt, prep, want_grad=False)[0]
-            ctx.pending = None
+            loss, ws = ops.loss_grad(kind, wrt, prep, want_grad=False)[0], None
+        ctx.has_ws = ws is not None
+        if ws is not None:
+            ctx.save_for_backward(x, ws)  # freed with the graph, like any saved activation
+        else:
+            ctx.save_for_backward(x)
         return loss
 
     @staticmethod
     def backward(ctx, d_loss):
         x = ctx.saved_tensors[0]
+        ws = ctx.saved_tensors[1] if ctx.has_ws else None
         if not torch.is_grad_enabled():
             # first order only (no create_graph): nobody will differentiate the gradient, so skip the nested autograd node
             # (one Function.apply, its context and saved tensors: ~20 us of host time per step)
-            if ctx.pending is not None:
-                loss, ws = ctx.pending
-                return ops.grad_resume(ctx.kind, ctx.wrt, ctx.prep, loss, ws, d_loss=d_loss), None, None, None
+            if ws is not None:
+                return ops.grad_resume(ctx.kind, ctx.wrt, ctx.prep, ws, d_loss=d_loss), None, None, None
             return ops.loss_grad(ctx.kind, ctx.wrt, ctx.prep, True, d_loss=d_loss)[1], None, None, None
-        return _CtcGradient.apply(x, d_loss, ctx.kind, ctx.wrt, ctx.prep, ctx.pending), None, None, None
+        return _CtcGradient.apply(x, d_loss, ctx.kind, ctx.wrt, ctx.prep, ws), None, None, None
 
 
-def _ctc(kind_name: str, wrt: int, labels, x, label_length, logit_length, blank_index) -> torch.Tensor:
+def _host_max(label_length):
+    """max(label_length) when the caller's copy lives on the host (NumPy array, list, CPU tensor): free, no device sync."""
+    if isinstance(label_length, torch.Tensor):
+        if label_length.is_cuda or label_length.numel() == 0:
+            return None
+        return int(label_length.max())
+    a = np.asarray(label_length)
+    return int(a.max()) if a.size else None
+
+
+def _ctc(kind_name: str, wrt: int, labels, x, label_length, logit_length, blank_index, max_label_length=None) -> torch.Tensor:
     x = _as_tensor(x)
     labels = _as_tensor(labels, torch.int32)
+    if max_label_length is None:
+        max_label_length = _host_max(label_length)
     label_length = _as_tensor(label_length, torch.int32)
     logit_length = _as_tensor(logit_length, torch.int32)
     _verify_inputs(labels, x, label_length, logit_length)
     kind = ops.KINDS[kind_name]
     # logits keep the producer's format where the kernels read it directly (bfloat16, time-major views): no copy
     prep = ops.Prepared(labels, x.detach(), label_length, logit_length, _blank(blank_index),
-                        keep_format=(wrt == _lib.WRT_LOGITS))
+                        keep_format=(wrt == _lib.WRT_LOGITS), host_max_label_length=max_label_length)
     return _CtcLoss.apply(x, kind, wrt, prep)
 
 
@@ -155,7 +170,7 @@ def _ctc(kind_name: str, wrt: int, labels, x, label_length, logit_length, blank_
 # public functions
 # --------------------------------------------------------------------------------------------------
 def classic_ctc_loss(labels: TensorLike, logits: TensorLike, label_length: TensorLike, logit_length: TensorLike,
-                     blank_index: Union[int, torch.Tensor] = 0) -> torch.Tensor:
+                     blank_index: Union[int, torch.Tensor] = 0, *, max_label_length: Optional[int] = None) -> torch.Tensor:
     """Classic CTC loss (repeated tokens without a blank in between are merged, then blanks are dropped;
     reference classic_ctc_loss.py:33-70).  Infeasible samples give loss = +inf with zero gradient.
 
@@ -165,16 +180,20 @@ def classic_ctc_loss(labels: TensorLike, logits: TensorLike, label_length: Tenso
         label_length: [batch] int32
         logit_length: [batch] int32
         blank_index:  integer >= 0 (or a scalar tensor)
+        max_label_length: (extension, keyword only) an upper bound on label_length known on the host.  The reference takes
+            the dynamic maximum (base_loss.py:482-486); here any bound >= it gives the same results and a tight one selects
+            the fastest kernel tier without a device -> host sync.  Not needed when label_length is passed as a NumPy array /
+            CPU tensor (its maximum is then taken on the host), nor for label tensors up to 128 wide.
     Returns: [batch] float32 samplewise loss
     """
-    return _ctc("classic", _lib.WRT_LOGITS, labels, logits, label_length, logit_length, blank_index)
+    return _ctc("classic", _lib.WRT_LOGITS, labels, logits, label_length, logit_length, blank_index, max_label_length)
 
 
 def simplified_ctc_loss(labels: TensorLike, logits: TensorLike, label_length: TensorLike, logit_length: TensorLike,
-                        blank_index: Union[int, torch.Tensor] = 0) -> torch.Tensor:
+                        blank_index: Union[int, torch.Tensor] = 0, *, max_label_length: Optional[int] = None) -> torch.Tensor:
     """Simplified CTC loss (blanks are dropped, repeated tokens are NOT merged; reference
     simplified_ctc_loss.py:32-67).  Same arguments and return value as classic_ctc_loss."""
-    return _ctc("simplified", _lib.WRT_LOGITS, labels, logits, label_length, logit_length, blank_index)
+    return _ctc("simplified", _lib.WRT_LOGITS, labels, logits, label_length, logit_length, blank_index, max_label_length)
 
 
 simple_ctc_loss = simplified_ctc_loss  # row label used by the reference's README.md:22 and tests/benchmark.py:72,98

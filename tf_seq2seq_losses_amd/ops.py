@@ -9,7 +9,21 @@ import torch
 from . import _lib
 
 KINDS = {"classic": _lib.CLASSIC, "simplified": _lib.SIMPLIFIED}
-FUSED_MAX_U = 512  # label positions the fused kernels hold (eight per lane); wider label tensors may still have short labels
+# Label tensors wider than this are worth one look at max(label_length): up to 128 positions run the fastest instantiation
+# (two positions per lane) whatever the width says; beyond, every doubling selects a slower tier (four / eight positions per
+# lane, then the three-kernel pipeline) although the labels inside may be short (tests/common.py:89-94 pads labels to T).
+WIDTH_WORTH_A_LOOK = 128
+_MAXLEN_CACHE = {}  # (data_ptr, version, numel, device) of a label_length tensor -> its maximum (one sync per distinct tensor)
+
+
+def _device_max_label_length(t: torch.Tensor) -> int:
+    key = (t.data_ptr(), t._version, t.numel(), t.device)
+    m = _MAXLEN_CACHE.get(key)
+    if m is None:
+        if len(_MAXLEN_CACHE) > 64:
+            _MAXLEN_CACHE.clear()
+        m = _MAXLEN_CACHE[key] = int(t.max().item())  # device -> host sync, once per tensor (pass max_label_length= to avoid it)
+    return m
 
 
 def _require_gpu(t: torch.Tensor) -> None:
@@ -33,7 +47,7 @@ class Prepared:
     keep_format=True a float32/bfloat16 tensor whose token axis is contiguous is passed as it is (time-major views,
     bfloat16 activations: ctc_amd_loss_grad_ex) -- only loss_grad takes such inputs, the other entry points use plain()."""
 
-    def __init__(self, labels, x, label_length, logit_length, blank_index, U=None, keep_format=False):
+    def __init__(self, labels, x, label_length, logit_length, blank_index, U=None, keep_format=False, host_max_label_length=None):
         _require_gpu(x)
         dev = x.device
         V = int(x.shape[2]) if x.dim() == 3 else 0
@@ -49,15 +63,17 @@ class Prepared:
         self.blank = int(blank_index)
         self.B, self.T, self.V = (int(s) for s in x.shape)
         self.stride = int(self.labels.shape[1])
-        # static bound on the label length: identical results to the reference's dynamic max(label_length)
-        # (base_loss.py:482-486) without a device->host sync.  Only when the label tensor is wider than the fused
-        # kernels' 256 positions (e.g. padded to a long frame count, tests/common.py:89-94) is the maximum fetched -- one
-        # small sync (not capturable into a graph) that lets such batches take the fused path when their labels are in
-        # fact short; pass U explicitly to avoid it.
+        # static bound on the label length: any U >= max(label_length) gives the reference's results (it uses the dynamic
+        # maximum, base_loss.py:482-486).  The width of the label tensor always works; a tighter bound selects a faster kernel
+        # tier.  Sources, in order: the caller's hint (`max_label_length=` of the public functions), the host copy of
+        # label_length when the caller passed one (free), and -- only for tensors wide enough that it matters -- the
+        # device-side maximum, fetched once per distinct label_length tensor (one sync, not capturable into a graph).
         if U is None:
             U = self.stride
-            if U > FUSED_MAX_U and self.label_length.numel() > 0:
-                U = max(0, min(U, int(self.label_length.max().item())))
+            if host_max_label_length is not None:
+                U = max(0, min(U, int(host_max_label_length)))
+            elif U > WIDTH_WORTH_A_LOOK and self.label_length.numel() > 0 and not torch.cuda.is_current_stream_capturing():
+                U = max(0, min(U, _device_max_label_length(self.label_length)))
         self.U = int(U)
         self.device = dev
 
@@ -79,14 +95,39 @@ class Prepared:
 
 _WS_BYTES = {}   # (what, kind, B, T, V, U) -> bytes: no ctypes round trip per call
 _WS_CACHE = {}   # (device, stream) -> the loss+gradient workspace last used there (reused while it is large enough)
+_PIPELINE = {}   # (kind, wrt, B, T, V, U) -> pipeline name of a contiguous float32 call
 
 
-def _workspace(what: int, kind: int, p: Prepared) -> torch.Tensor:
-    key = (what, kind, p.B, p.T, p.V, p.U)
+def _ws_bytes(what: int, kind: int, p: "Prepared") -> int:
+    key = (what, kind, p.B, p.T, p.V, p.U, _lib.override_generation)
     n = _WS_BYTES.get(key)
     if n is None:
         n = _WS_BYTES[key] = _lib.workspace_bytes(what, kind, p.B, p.T, p.V, p.U)
-    if what != _lib.WS_LOSS_GRAD:
+    return n
+
+
+def _loss_grad_selector(wrt: int, p: "Prepared") -> int:
+    """Workspace selector of a loss+gradient call: the pipeline's own (small) layout for logits input in a format the
+    fused tiers read (float32; bfloat16 with 8-byte aligned rows), the conservative one otherwise (include/ctc_amd.h)."""
+    if wrt != _lib.WRT_LOGITS:
+        return _lib.WS_LOSS_GRAD
+    x = p.x
+    if x.dtype == torch.bfloat16 and ((p.V | x.stride(0) | x.stride(1)) & 3 or x.data_ptr() & 7):
+        return _lib.WS_LOSS_GRAD
+    return _lib.WS_LOSS_GRAD_LOGITS
+
+
+def pipeline_of(kind: int, wrt: int, p: "Prepared") -> str:
+    key = (kind, wrt, p.B, p.T, p.V, p.U, _lib.override_generation)
+    name = _PIPELINE.get(key)
+    if name is None:
+        name = _PIPELINE[key] = _lib.pipeline_name(kind, wrt, p.B, p.T, p.V, p.U, True)
+    return name
+
+
+def _workspace(what: int, kind: int, p: Prepared) -> torch.Tensor:
+    n = _ws_bytes(what, kind, p)
+    if what not in (_lib.WS_LOSS_GRAD, _lib.WS_LOSS_GRAD_LOGITS):
         return torch.empty(max(n, 1), dtype=torch.uint8, device=p.device)
     # The loss+gradient workspace is scratch that lives only for the duration of one call.  Calls on one stream are
     # ordered, so they can share one buffer; another stream gets its own.
@@ -135,7 +176,7 @@ def loss_grad(kind: int, wrt: int, p: Prepared, want_grad: bool, d_loss: Optiona
         grad = torch.empty((p.B, p.T, p.V), dtype=torch.float32, device=p.device) if want_grad else None
     if p.B == 0:
         return loss, grad
-    ws = workspace if workspace is not None else _workspace(_lib.WS_LOSS_GRAD, kind, p)
+    ws = workspace if workspace is not None else _workspace(_loss_grad_selector(wrt, p), kind, p)
     if d_loss is not None:
         d_loss = d_loss.to(device=p.device, dtype=torch.float32).contiguous()
     with _on_device(p.device):
@@ -166,7 +207,7 @@ def loss_grad_sum(kind: int, wrt: int, p: Prepared, sum2: torch.Tensor, zero_nex
         grad = torch.empty_strided(p.x.shape, p.x.stride(), dtype=p.x.dtype, device=p.device) if want_grad else None
     else:
         grad = torch.empty((p.B, p.T, p.V), dtype=torch.float32, device=p.device) if want_grad else None
-    ws = _workspace(_lib.WS_LOSS_GRAD, kind, p)
+    ws = _workspace(_loss_grad_selector(wrt, p), kind, p)
     if d_loss is not None:
         d_loss = d_loss.to(device=p.device, dtype=torch.float32).contiguous()
     dt = _DTYPES[p.x.dtype]
@@ -180,20 +221,27 @@ def loss_grad_sum(kind: int, wrt: int, p: Prepared, sum2: torch.Tensor, zero_nex
     return loss, grad
 
 
-def loss_forward(kind: int, wrt: int, p: Prepared) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Loss only, with a workspace of its own that grad_resume continues from (returned; keep it alive until then)."""
-    n = _WS_BYTES.get((_lib.WS_LOSS_GRAD, kind, p.B, p.T, p.V, p.U))
-    if n is None:
-        n = _WS_BYTES[(_lib.WS_LOSS_GRAD, kind, p.B, p.T, p.V, p.U)] = _lib.workspace_bytes(_lib.WS_LOSS_GRAD, kind, p.B, p.T, p.V, p.U)
-    ws = torch.empty(max(n, 1), dtype=torch.uint8, device=p.device)
+def loss_forward(kind: int, wrt: int, p: Prepared, keep_always: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Loss only.  Where the two-call form exists (the linear-domain fused tier) the call gets a workspace of its own that
+    grad_resume continues from (returned; keep it alive until then: checkpoint rows only, ~64 MB at the north-star shape);
+    every other pipeline would recompute everything in the second call anyway, so nothing is kept (None) unless
+    keep_always (the parity tests call ctc_amd_grad_resume behind every pipeline)."""
+    sel = _loss_grad_selector(wrt, p)
+    if p.B == 0 or (not keep_always and (sel != _lib.WS_LOSS_GRAD_LOGITS or pipeline_of(kind, wrt, p) != "fused6")):
+        return loss_grad(kind, wrt, p, False)[0], None
+    ws = torch.empty(max(_ws_bytes(sel, kind, p), 1), dtype=torch.uint8, device=p.device)
     loss, _ = loss_grad(kind, wrt, p, False, workspace=ws)
     return loss, ws
 
 
-def grad_resume(kind: int, wrt: int, p: Prepared, loss: torch.Tensor, ws: torch.Tensor,
-                d_loss: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Gradient for the loss that loss_forward computed into `ws` (ctc_amd_grad_resume), weighted by d_loss."""
+def grad_resume(kind: int, wrt: int, p: Prepared, ws: torch.Tensor, d_loss: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Gradient for the loss that loss_forward computed into `ws` (ctc_amd_grad_resume), weighted by d_loss.  The losses the
+    call rewrites (utterances redone in the log domain) go to a scratch buffer: the tensor the forward pass returned to the
+    user is never written again."""
+    if ws is None:  # the forward call kept nothing (its pipeline has no two-call form): one loss+gradient call
+        return loss_grad(kind, wrt, p, True, d_loss=d_loss)[1]
     lib = _lib.load()
+    loss = torch.empty(p.B, dtype=torch.float32, device=p.device)
     if p.native:
         grad = torch.empty_strided(p.x.shape, p.x.stride(), dtype=p.x.dtype, device=p.device)
     else:
@@ -210,6 +258,12 @@ def grad_resume(kind: int, wrt: int, p: Prepared, loss: torch.Tensor, ws: torch.
                                      ws.data_ptr(), ws.numel(), _stream(p.device))
     _lib.check(rc, "ctc_amd_grad_resume")
     return grad
+
+
+def fused_flags(ws: torch.Tensor, kind: int, p: Prepared) -> torch.Tensor:
+    """Diagnostic: int32[B] flag words the linear-domain kernel left in `ws` (0 = linear domain, else redone in the log domain)."""
+    off = _lib.flags_offset(kind, p.B, p.T, p.V, p.U)
+    return ws[off:off + 4 * p.B].view(torch.int32)
 
 
 def alpha_beta(kind: int, wrt: int, p: Prepared):
