@@ -206,10 +206,11 @@ def emulated_collective_table(lib, step_sum_factory, device, steps=120):
     item 5): does a kernel of RCCL's footprint run beside 256 workgroups that hold 159 000 of 163 840 bytes of LDS each?"""
     from tf_seq2seq_losses_amd import dist as cdist
     out = {}
-    for name, depth, emulate in (("no_collective", 1, False), ("emulated_depth1", 1, True), ("emulated_depth2", 2, True)):
+    for name, depth, emu_kw in (("no_collective", 1, None), ("emulated_depth1", 1, {}), ("emulated_depth2", 2, {}),
+                                ("emulated_depth1_one_wave_no_lds", 1, dict(threads=64, lds=0))):
         step = step_sum_factory(depth + 2)
-        emu = EmulatedAllReduce(lib, device) if emulate else None
-        cdist.pipelined_steps(step, 20, reduced=True, depth=depth, all_reduce=emu)
+        emu = EmulatedAllReduce(lib, device, **emu_kw) if emu_kw is not None else None
+        prewarm(lambda: cdist.pipelined_steps(step, 4, reduced=True, depth=depth, all_reduce=emu), 40.0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -283,6 +284,7 @@ def secondary(device, rank):
         host, dev = make_inputs(B, T, U, V, seed=seed, ragged=ragged, device=device)
         step = _lossgrad_callable(lib, _lib, ops, ops.KINDS[kind_name], dev, B, T, U, V)
         d = {}
+        prewarm(step, 40.0)  # (the GPU idled through the CPU baseline: every entry gets its own warm start)
         kms, wms = _events_ms(step, steps, 10, d)
         frames = int(host["logit_length"].sum())
         out[name] = dict(workload=f"{kind_name}_ctc_loss loss+grad B={B} T={T} U={U} V={V} fp32 {'ragged' if ragged else 'full-length'}",
@@ -303,6 +305,7 @@ def secondary(device, rank):
     def dropin():
         loss = ctc.classic_ctc_loss(dev["labels"], x, dev["label_length"], dev["logit_length"], 0)
         return torch.autograd.grad(loss.mean(), x)[0]
+    prewarm(dropin, 40.0)
     kms, wms = _events_ms(dropin, 50, 10)
     out["dropin_autograd"] = dict(workload=f"classic_ctc_loss(...) + autograd.grad(loss.mean(), logits) through the Python mirror, B={B} T={T} U={U} V={V}",
                                   value=B / (wms * 1e-3), unit="utterances/s", ms_per_step=wms,
@@ -361,9 +364,10 @@ def reference_table(device):
         lp = torch.log_softmax(x, dim=2).transpose(0, 1)
         return torch.nn.functional.ctc_loss(lp, labels.long(), tl.long(), ll.long(), blank=blank, reduction="none")
 
-    def wall(fn, steps=30, warmup=5):
+    def wall(fn, steps=100, warmup=5):
         for _ in range(warmup):
             fn()
+        prewarm(fn, 20.0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -371,7 +375,7 @@ def reference_table(device):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps * 1e3
     rows = {}
-    for name, fn in (("torch.nn.functional.ctc_loss", torch_ctc), ("classic_ctc_loss", ctc.classic_ctc_loss), ("simple_ctc_loss", ctc.simple_ctc_loss)):
+    for name, fn in (("classic_ctc_loss", ctc.classic_ctc_loss), ("simple_ctc_loss", ctc.simple_ctc_loss), ("torch.nn.functional.ctc_loss", torch_ctc)):
         def forward():
             with torch.no_grad():
                 return fn(labels, logits, ll, tl, 0)
@@ -380,9 +384,10 @@ def reference_table(device):
             x = logits.detach().requires_grad_(True)
             loss = fn(labels, x, ll, tl, 0)
             return torch.autograd.grad(loss.sum(), x)[0]
-        rows[name] = dict(forward_ms=round(wall(forward), 4), forward_gradient_ms=round(wall(gradient), 4))
+        # (best of two passes: the first pass after another implementation's run pays for its allocator state)
+        rows[name] = dict(forward_ms=round(min(wall(forward), wall(forward)), 4), forward_gradient_ms=round(min(wall(gradient), wall(gradient)), 4))
     return dict(workload=f"reference README table: B={B} T={T} V={V}, ragged lengths, label tensor {T} wide (labels <= {int(ll_h.max())}), "
-                         "wall clock per call incl. Python, 30 calls after 5", rows=rows)
+                         "wall clock per call incl. Python, best of two passes of 100 calls after a 20 ms warm start", rows=rows)
 
 
 def main():
@@ -401,12 +406,12 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (simplified, ragged, drop-in autograd, HVP, Hessian)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="element type of logits and gradient (producer format)")
     ap.add_argument("--time-major", action="store_true", help="logits stored [T,B,V] (producer format), passed as a strided view")
-    ap.add_argument("--pipeline-depth", type=int, default=1,
+    ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="steps the all-reduce of sum(loss) may lag behind the loss kernel (dist.pipelined_steps depth)")
     ap.add_argument("--emulate-collective", action="store_true",
                     help="N = 1 only: stand in for RCCL's all-reduce with a kernel of its footprint on a second stream (ctc_amd_probe_spin), "
                          "ordered as the real one is")
-    ap.add_argument("--prewarm-ms", type=float, default=100.0,
+    ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="after the --warmup steps, keep launching the timed kernel until this much device time has passed (untimed; 0 = off)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse ranks that share one GPU)")

@@ -93,6 +93,7 @@ const char *ctc_amd_pipeline_name(int kind, int wrt, int B, int T, int V, int U,
  * Diagnostic override, for parity tests and benchmarks only (process-wide; set it between calls, not during one):
  *   key "pipeline": "" (best eligible tier, default), "v1", "fused2", "fused5" -- forces a lower tier of ctc_amd_loss_grad
  *   key "hessian":  "" (default) or "slab" -- the general Hessian kernel also for labels of <= 32 positions
+ *   key "hvp":      "" (default) or "v1"   -- the log-domain Hessian-vector pipeline also where the fused kernel applies
  * The library never reads the environment.  Returns CTC_AMD_EINVAL for an unknown key or value.
  */
 int ctc_amd_debug_override(const char *key /*host*/, const char *value /*host*/);
@@ -167,6 +168,22 @@ int ctc_amd_alpha_beta(int kind, int wrt,
                        int B, int T, int V, int U,
                        float *loss, float *alpha, float *beta,
                        void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * lg[B][T][V] = natural log of the posterior P(frame t emits token k | label) -- minus the gradient w.r.t. log-probabilities,
+ * in log space: finite where the float32 gradient has underflowed (a posterior of e^-150 is returned as -150), -inf for
+ * tokens no lattice state emits, for frames beyond logit_length and for infeasible samples.  Also writes loss[B].
+ * Replaces: loss_data.logarithmic_logproba_gradient (base_loss.py:270-298): the segment log-sum-exp of
+ * _combine_transition_probabilities(alpha[:, :-1], beta[:, 1:]) by token (base_loss.py:420-468, tools.py:74-119).
+ * Debug / analysis entry point like ctc_amd_alpha_beta (three-kernel pipeline, full lattice rows).  V <= 8192.
+ * Workspace: CTC_AMD_WS_ALPHA_BETA.
+ */
+int ctc_amd_log_posterior(int kind, int wrt,
+                          const float *logits, const int32_t *labels, int label_stride,
+                          const int32_t *label_length, const int32_t *logit_length, int blank_index,
+                          int B, int T, int V, int U,
+                          float *loss, float *lg,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Dense Hessian hess[B][T][V][T][V] (the O(l^4) path), plus loss and gradient (grad may be NULL).

@@ -15,7 +15,9 @@ for n in names:
     path = os.path.join(ROOT, "tf_seq2seq_losses_amd", "libctc_amd.so") if n == "tree" else os.path.join(ROOT, "scratch", f"libctc_v_{n}.so")
     lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in _lib.SIGNATURES.items():
-        fn = getattr(lib, name); fn.restype = restype; fn.argtypes = argtypes
+        fn = getattr(lib, name, None)  # (older builds lack the newer entry points)
+        if fn is not None:
+            fn.restype = restype; fn.argtypes = argtypes
     libs.append(lib)
 dev = torch.device("cuda:0")
 host, d = bench.make_inputs(B, T, U, V, 2, False, dev)

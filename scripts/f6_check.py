@@ -12,16 +12,7 @@ dev = torch.device("cuda:0")
 
 
 def flags_of(ws, kind, B, T, V, U):
-    # Layout::off_flags: recompute the offsets like make_layout (ctc_common.h)
-    al = lambda x: (x + 255) & ~255
-    nl = 1
-    while nl * 64 < U:
-        nl *= 2
-    UP = nl * 64; ERS = UP + 4; SRS = (2 * UP if kind == 0 else UP) + 8
-    o = 0
-    o = al(o + B * T * ERS * 4); o = al(o + B * (T + 1) * SRS * 4); o = al(o + B * (T + 1) * SRS * 4)
-    o = al(o + B * 8); o = al(o + B * 2 * 1024); o = al(o + B * 4)
-    o = al(o + B * 2 * ((T + 2) // 3 + 3) * 64 * 4)
+    o = _lib.flags_offset(kind, B, T, V, U)  # Layout::off_flags of the pipeline's own layout (ctc_amd_debug_flags_offset)
     if os.environ.get("F6_STAMPS"):
         st = ws[o + 4 * B:o + 4 * B + B * 512].view(torch.int64).cpu().numpy().reshape(B, 16, 4)[:, :12]
         med = np.median(st, axis=0)

@@ -43,6 +43,26 @@ def fb_hint():
     loss = ctc.classic_ctc_loss(labels, x, ll, tl, 0, max_label_length=126)
     return torch.autograd.grad(loss.sum(), x)[0]
 
+from tf_seq2seq_losses_amd import ops, _lib
+for name, kw in (("default", {}), ("hinted", dict(host_max_label_length=126))):
+    p = ops.Prepared(labels, logits, ll, tl, 0, **kw)
+    print(name, "U", p.U, "pipeline", _lib.pipeline_name(0, 0, p.B, p.T, p.V, p.U, True), "ws", _lib.workspace_bytes(_lib.WS_LOSS_GRAD_LOGITS, 0, p.B, p.T, p.V, p.U))
+assert torch.equal(fb(), fb_hint())
+
+
+def dev_us(fn, n=200):
+    for _ in range(20): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+for rep in range(2):
+    for name, fn in (("fb", fb), ("fb_hint", fb_hint), ("fb_ref", fb_ref), ("fwd", fwd)):
+        print("rep %d %-8s wall %.4f ms  submit %.4f ms  device %.1f us per call" % (rep, name, t(fn), submit(fn), dev_us(fn)))
 print("forward (no grad)               %.4f ms   submit %.4f" % (t(fwd), submit(fwd)))
 print("forward + grad(loss.sum())      %.4f ms   submit %.4f" % (t(fb), submit(fb)))
 print("forward + grad, table recipe    %.4f ms   submit %.4f" % (t(fb_ref), submit(fb_ref)))

@@ -121,8 +121,8 @@ def test_long_labels_on_the_linear_kernel_at_full_length(kind, T, U):
 @pytest.mark.parametrize("kind", ["classic", "simplified"])
 def test_linear_kernel_flags_what_it_cannot_hold_and_nothing_else(kind):
     """Benign logits (N(0,1), the benchmark distribution): no utterance is flagged and the gradient is the float64 one to
-    1e-5 at T = 1000 (the log-domain kernel: 2.6e-4).  Sharp logits (N(0, 3^2) at T = 1000), -inf columns and 1e10:
-    flagged, redone in the log domain, still the oracle's answer."""
+    1e-5 at T = 1000 (the log-domain kernel: 2.6e-4).  -inf columns and 1e10: flagged, redone in the log domain, still the
+    oracle's answer; sharp logits (N(0, 3^2) at T = 1000): held in the linear domain at 1e-4, or flagged and redone."""
     from tf_seq2seq_losses_amd import ops, _lib
     k = ops.KINDS[kind]
     B, T, U, V = 16, 1000, 128, 256
@@ -143,7 +143,10 @@ def test_linear_kernel_flags_what_it_cannot_hold_and_nothing_else(kind):
     labels6 = labels[:6].copy()
     ws = torch.zeros(_lib.workspace_bytes(_lib.WS_LOSS_GRAD, k, 6, T, V, U), dtype=torch.uint8, device=_dev())
     loss, grad = ops.loss_grad(k, _lib.WRT_LOGITS, p, True, workspace=ws)
-    assert _flags(ws, k, 6, T, V, U).all()
+    fl = _flags(ws, k, 6, T, V, U)
+    # -inf columns and a 1e10 logit leave the format; N(0, 3^2) logits did too in round 2 (posterior scale beyond 2^90, D5) and
+    # are held since the scale is applied in two factors (KK_MAX in ctc_fused6.hip) -- whichever way, the answer is the oracle's
+    assert fl[4] != 0 and fl[5] != 0
     # the in-launch loss sum when utterances are flagged late (phase 2) or early: what was added at the meeting point is taken
     # back and the log-domain loss added instead
     sum2 = torch.zeros(2, dtype=torch.int64, device=_dev())
@@ -161,8 +164,9 @@ def test_linear_kernel_flags_what_it_cannot_hold_and_nothing_else(kind):
     # of the gradient are meaningful there -- tests/test_gpu_parity.py::test_extreme_logits)
     gn = grad.cpu().numpy()
     assert np.isfinite(gn).all()
-    cmp = fin.copy(); cmp[5] = False
-    assert np.abs(gn[cmp] - rg[cmp]).max() < 2e-3
+    for b in range(5):
+        if fin[b]:  # linear domain: north_star's tolerance; redone in the log domain: that kernel's accuracy with sharp logits
+            assert np.abs(gn[b] - rg[b]).max() < (1e-4 if fl[b] == 0 else 2e-3), (b, int(fl[b]), np.abs(gn[b] - rg[b]).max())
 
 
 def test_check_labels():

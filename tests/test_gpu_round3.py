@@ -76,7 +76,13 @@ def test_label_length_bound_sources_agree():
     dev_ll = _t(ll)
     cached = ops.Prepared(_t(labels), x, dev_ll, _t(tl), 0)                 # device-side maximum, fetched once
     assert cached.U == int(ll.max())
-    assert (dev_ll.data_ptr(), dev_ll._version, dev_ll.numel(), dev_ll.device) in ops._MAXLEN_CACHE
+    assert ops._MAXLEN_CACHE[id(dev_ll)][0]() is dev_ll and ops._MAXLEN_CACHE[id(dev_ll)][2] == int(ll.max())
+    # the cache is keyed on the tensor object, not on its address: another batch's lengths at the same address are looked at anew
+    other = dev_ll.clone()
+    del dev_ll
+    other.copy_(_t(np.minimum(ll, 50)))
+    assert ops.Prepared(_t(labels), x, other, _t(tl), 0).U == 50
+    dev_ll = _t(ll)
     hinted = ops.Prepared(_t(labels), x, dev_ll, _t(tl), 0, host_max_label_length=200)
     assert hinted.U == 200
     ref = ops.loss_grad(0, 0, wide, True)
@@ -185,3 +191,69 @@ def test_unaligned_base_pointers_on_the_other_entry_points(kind):
                          vec.data_ptr(), loss.data_ptr(), None, out.data_ptr(), wsh.data_ptr(), nh, st)
     assert rc == 0, lib.ctc_amd_last_error()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_log_posterior_stays_finite_where_the_gradient_underflows(kind):
+    """logarithmic_logproba_gradient (base_loss.py:270-298) is computed in log space: posteriors far below float32's smallest
+    number (e^-150, e^-300) come back as finite logs, equal to the float64 oracle's; the linear gradient there is 0."""
+    import tf_seq2seq_losses_amd as ctc
+    rng = np.random.default_rng(2)
+    B, T, V, U = 3, 12, 6, 4
+    logits = rng.standard_normal((B, T, V)).astype(np.float32)
+    labels = rng.integers(1, V, (B, U)).astype(np.int32)
+    labels[0] = [1, 2, 3, 4]
+    ll = np.array([4, 3, 2], np.int32)
+    tl = np.array([12, 10, 12], np.int32)
+    logits[0, 0, 1] = -150.0          # the first label at the first frame: possible, but only at e^-150
+    logits[0, 5, 3] = -300.0
+    logits[1, 2, labels[1, 0]] = -200.0
+    lp = logits.astype(np.float64)
+    lp = (lp - np.log(np.exp(lp - lp.max(2, keepdims=True)).sum(2, keepdims=True)) - lp.max(2, keepdims=True)).astype(np.float32)
+    cls = ctc.ClassicCtcLossData if kind == "classic" else ctc.SimplifiedCtcLossData
+    d = cls(_t(labels), _t(lp), _t(ll), _t(tl), 0)
+    lg = d.logarithmic_logproba_gradient.cpu().numpy()
+    ref = O.ctc_loss_from_logproba(kind, labels, lp, ll, tl, 0) if hasattr(O, "ctc_loss_from_logproba") else None
+    if ref is None:
+        ocls = O.ClassicCtcLossData if kind == "classic" else O.SimplifiedCtcLossData
+        ref = ocls(labels, lp.astype(np.float64), ll, tl, 0)
+    want = ref.logarithmic_logproba_gradient
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(lg), fin)
+    assert want[0, 0, 1] < -140 and np.isfinite(lg[0, 0, 1])          # the e^-150 entry exists and is finite here
+    assert want[0, 5, 3] < -250 and np.isfinite(lg[0, 5, 3])
+    err = np.abs(lg[fin] - want[fin])
+    assert (err / np.maximum(1.0, np.abs(want[fin]))).max() < 2e-5, err.max()   # float32 logs: relative
+    assert np.abs(np.exp(lg[fin]) - np.exp(want[fin])).max() < 1e-5               # and the posteriors themselves
+    g = d.gradient.cpu().numpy()
+    assert g[0, 0, 1] == 0.0                                                       # the linear gradient has underflowed
+    assert np.abs(g + np.where(fin, np.exp(want), 0.0)).max() < TOL
+
+
+@pytest.mark.parametrize("kind", ["classic", "simplified"])
+def test_long_benign_utterances_stay_on_the_linear_kernel(kind):
+    """N(0,1) logits at T = 5000 (B = 64, U = 128): no utterance is flagged -- round 2 sent 1 in 64 to the log-domain roles
+    here (posterior scale beyond 2^90 in one factor, D5), which cost the call a second pass -- and the gradient keeps 1e-4
+    against the float64 oracle."""
+    from tf_seq2seq_losses_amd import ops, _lib
+    k = ops.KINDS[kind]
+    B, T, U, V = 64, 5000, 128, 256
+    rng = np.random.default_rng(17)
+    logits = rng.standard_normal((B, T, V), dtype=np.float32)
+    labels = rng.integers(1, V, (B, U), dtype=np.int32)
+    ll, tl = np.full(B, U, np.int32), np.full(B, T, np.int32)
+    p = ops.Prepared(_t(labels), _t(logits), _t(ll), _t(tl), 0, U=U)
+    assert _lib.pipeline_name(k, 0, B, T, V, U, True) == "fused6"
+    ws = torch.zeros(_lib.workspace_bytes(_lib.WS_LOSS_GRAD_LOGITS, k, B, T, V, U), dtype=torch.uint8, device=_dev())
+    loss, grad = ops.loss_grad(k, _lib.WRT_LOGITS, p, True, workspace=ws)
+    flags = ops.fused_flags(ws, k, p).cpu().numpy()
+    assert not flags.any(), flags
+    m = 6
+    rl, rg = C.loss_grad(kind, labels[:m], logits[:m], ll[:m], tl[:m], 0)
+    assert (np.abs(loss[:m].cpu().numpy() - rl) / np.abs(rl)).max() < 1e-6
+    assert np.abs(grad[:m].cpu().numpy() - rg).max() < TOL
+    # the two-call form takes the same route
+    loss2, ws2 = ops.loss_forward(k, _lib.WRT_LOGITS, p)
+    grad2 = ops.grad_resume(k, _lib.WRT_LOGITS, p, ws2)
+    assert not ops.fused_flags(ws2, k, p).cpu().numpy().any()
+    assert torch.equal(grad, grad2)

@@ -56,6 +56,7 @@ SIGNATURES = {
                                      _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "ctc_amd_alpha_beta": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "ctc_amd_hessian": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "ctc_amd_log_posterior": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "ctc_amd_hvp": (_c_int, _COMMON + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
 }
 

@@ -6,11 +6,13 @@
 
 #include "ctc_amd.h"
 #include "ctc_common.h"
+#include "ctc_hvp_fused.h"
 
 namespace ctc {
-hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *loss, int ndir, hipStream_t st);
+hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *loss, int ndir, hipStream_t st, const int *only_if = nullptr);
 hipError_t run_grad(const Problem &p, const Layout &L, char *ws, const float *d_loss, float *grad, hipStream_t st);
 hipError_t run_sum_loss_fixed(const float *loss, int B, long long *acc, long long *zero_next, hipStream_t st);
+hipError_t run_log_posterior(const Problem &p, const Layout &L, char *ws, float *out, hipStream_t st);
 hipError_t run_convert(const Problem &p, const Layout &L, char *ws, float *alpha_out, float *beta_out, hipStream_t st);
 hipError_t run_fused_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 hipError_t run_fused_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
@@ -70,7 +72,11 @@ size_t hvp_extra_bytes(int kind, int B, int T, int V, int U);
 // diagnostic overrides (ctc_amd_debug_override): process-wide, written only by tests / benchmarks between calls
 int g_force_pipeline = 0;      // 0 = best eligible tier, 1 = v1, 2 = fused2, 5 = fused5 (log domain)
 int g_force_hessian_slab = 0;  // 1 = the general one-slab-per-wavefront Hessian kernel also for short labels
-hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec, float *out, hipStream_t st);
+int g_force_hvp_v1 = 0;        // 1 = the log-domain Hessian-vector pipeline also where the fused kernel applies
+hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec, float *out, hipStream_t st, const int *only_if = nullptr);
+hipError_t run_hvp_fused_classic(const Problem &p, char *ws_fused, const float *vec, float *loss, float *out, hipStream_t st);
+hipError_t run_hvp_fused_simplified(const Problem &p, char *ws_fused, const float *vec, float *loss, float *out, hipStream_t st);
+size_t hvp_fused_offset(int kind, int B, int T, int U);
 hipError_t run_reduce_loss(const float *loss, int B, float *out, hipStream_t st);
 hipError_t run_probe_copy(void *dst, const void *src, size_t bytes, hipStream_t st);
 hipError_t run_probe_spin(int threads, int lds_bytes, float us, hipStream_t st);
@@ -166,6 +172,11 @@ int ctc_amd_debug_override(const char *key, const char *value) {
   if (!strcmp(key, "hessian")) {
     if (strcmp(value, "") && strcmp(value, "slab")) return fail(CTC_AMD_EINVAL, "hessian override must be \"\" or \"slab\", got \"%s\"", value);
     ctc::g_force_hessian_slab = !strcmp(value, "slab");
+    return CTC_AMD_OK;
+  }
+  if (!strcmp(key, "hvp")) {
+    if (strcmp(value, "") && strcmp(value, "v1")) return fail(CTC_AMD_EINVAL, "hvp override must be \"\" or \"v1\", got \"%s\"", value);
+    ctc::g_force_hvp_v1 = !strcmp(value, "v1");
     return CTC_AMD_OK;
   }
   return fail(CTC_AMD_EINVAL, "unknown override key \"%s\"", key);
@@ -390,6 +401,25 @@ int ctc_amd_alpha_beta(int kind, int wrt, const float *logits, const int32_t *la
   return CTC_AMD_OK;
 }
 
+int ctc_amd_log_posterior(int kind, int wrt, const float *logits, const int32_t *labels, int label_stride,
+                          const int32_t *label_length, const int32_t *logit_length, int blank_index, int B, int T, int V,
+                          int U, float *loss, float *lg, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = check_common(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
+  if (rc) return rc;
+  if (B == 0) return CTC_AMD_OK;
+  if (!loss || (T > 0 && !lg)) return fail(CTC_AMD_EINVAL, "null output pointer");
+  if (V > 8192) return fail(CTC_AMD_EINVAL, "V=%d exceeds the supported maximum 8192 of ctc_amd_log_posterior", V);
+  ctc::Layout L = ctc::make_layout(kind, B, T, U, 0);
+  if (!workspace || workspace_bytes < L.total) return fail(CTC_AMD_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
+  ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = ctc::run_emit_scan(p, L, static_cast<char *>(workspace), loss, 2, st);
+  if (e != hipSuccess) return hip_fail(e, "emit/scan launch");
+  e = ctc::run_log_posterior(p, L, static_cast<char *>(workspace), lg, st);
+  if (e != hipSuccess) return hip_fail(e, "log posterior launch");
+  return CTC_AMD_OK;
+}
+
 int ctc_amd_hessian(int kind, int wrt, const float *logits, const int32_t *labels, int label_stride,
                     const int32_t *label_length, const int32_t *logit_length, int blank_index, int B, int T, int V,
                     int U, float *loss, float *grad, float *hess, void *workspace, size_t workspace_bytes,
@@ -438,13 +468,22 @@ int ctc_amd_hvp(int kind, int wrt, const float *logits, const int32_t *labels, i
   ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
   hipStream_t st = static_cast<hipStream_t>(stream);
   char *ws = static_cast<char *>(workspace);
-  hipError_t e = ctc::run_emit_scan(p, L, ws, loss, 2, st);
+  // The fused linear-domain kernel (ctc_hvp_fused.hip) where its instantiations apply; it leaves a flag per utterance, and the
+  // log-domain pipeline below then runs for the flagged ones only (normally none: five launches that find nothing to do).
+  const int *only_if = nullptr;
+  if (!grad && !ctc::g_force_hvp_v1 && ctc::hvp_fused_shape(wrt, B, T, V, U)) {
+    char *wsf = ws + L.off_extra + ctc::hvp_fused_offset(kind, B, T, U);
+    hipError_t ef = kind == 0 ? ctc::run_hvp_fused_classic(p, wsf, vec, loss, out, st) : ctc::run_hvp_fused_simplified(p, wsf, vec, loss, out, st);
+    if (ef != hipSuccess) return hip_fail(ef, "fused hvp launch");
+    only_if = reinterpret_cast<const int *>(wsf + ctc::make_hvp_fused_layout(B, T, U).off_flags);
+  }
+  hipError_t e = ctc::run_emit_scan(p, L, ws, loss, 2, st, only_if);
   if (e != hipSuccess) return hip_fail(e, "emit/scan launch");
   if (grad) {
     e = ctc::run_grad(p, L, ws, nullptr, grad, st);
     if (e != hipSuccess) return hip_fail(e, "grad launch");
   }
-  e = ctc::run_hvp(p, L, ws, vec, out, st);
+  e = ctc::run_hvp(p, L, ws, vec, out, st, only_if);
   if (e != hipSuccess) return hip_fail(e, "hvp launch");
   return CTC_AMD_OK;
 }

@@ -63,10 +63,16 @@ constexpr int GAP_WIDE = 64;      // ... when ONE level suffices (a lane of 4 or
 // and every loss-only call at U > 256 went to the log domain.)
 constexpr int DOWN_MAX = 96;      // D3
 constexpr int DECAY_MAX = 96;     // D4
-constexpr int KK_MAX = 90;        // D5: posterior scale 2^KK_MAX at most.  The posterior of a state is (alpha mantissa)(beta
+constexpr int KK_MAX = 90;        // Posterior scale 2^KK_MAX at most in ONE factor.  The posterior of a state is (alpha mantissa)(beta
                                   // mantissa) 2^(kA + kB - log2 P); the mantissa PRODUCT underflows below 2^-126, which is harmless
                                   // while the scale stays below 2^90 (the lost term is < 2^-5 units of 2^-30) and fatal beyond --
-                                  // sharp logits on a nearly forced alignment get there in the frames just before a renormalisation
+                                  // sharp logits on a nearly forced alignment get there in the frames just before a renormalisation,
+                                  // and so do benign long utterances (T >= 3000: a lane whose two label positions differ by more than
+                                  // 2^90 in alpha and by as much the other way in beta while the alignment crosses between them).
+                                  // Beyond KK_MAX the scale is applied in TWO factors: the excess 2^(k - KK_MAX) goes onto the chain's
+                                  // own operand BEFORE the product (then nothing that matters underflows), the rest after it as before;
+                                  // a wave-uniform branch per frame, taken only while some lane of the wavefront needs it.
+constexpr int KK_MAX2 = 200;      // D5: beyond this even the pre-scaled operand would leave float32
 constexpr float EMIS_MIN = 7.52316384526264e-37f;  // 2^-120 (D2)
 
 #ifdef CTC_F6_STAMPS
@@ -355,8 +361,8 @@ struct Chain {
     float m = c[0];
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      m = fmaxf(m, c[j]);
-      if constexpr (KIND == 0) m = fmaxf(m, o[j]);
+      if constexpr (KIND == 0) m = (j == 0) ? vmax_raw(m, o[0]) : vmax3_raw(m, c[j], o[j]);
+      else if (j > 0) m = vmax_raw(m, c[j]);
     }
     const bool live = m > 0.f;
     const int fe = frexp_e(m);
@@ -518,21 +524,26 @@ struct Rows {
 
   // Q frames at once (phase 1): row maximum and sum of exponentials by batched DPP reductions (ctc_dpp_batch.h), then the
   // gathers.  Outputs per frame: emissions, mxl = rowmax * log2 e, inv = 1 / sum exp, l2s = log2 sum exp.
+  // Q frames at once (phase 1): row maximum and sum of exponentials by batched reductions, then the gathers.  Outputs per frame:
+  // emissions, mxl = rowmax * log2 e, sm = sum exp (the caller takes ONE reciprocal per block, on the lanes that keep the
+  // statistics); and l2s_all = log2 of the PRODUCT of the Q sums (one logarithm for the Q frames: each sum lies in [1, V], so
+  // the product of four stays far inside float32) -- transcendentals are quarter rate, 6 of them per frame were 28 % of the
+  // E stage's issue time.
   template <int Q>
-  __device__ __forceinline__ void emit_n(const float4 (&xr)[Q][VPL], Emis<NL> (&e)[Q], float (&mxl)[Q], float (&inv)[Q], float (&l2s)[Q]) const {
+  __device__ __forceinline__ void emit_n(const float4 (&xr)[Q][VPL], Emis<NL> (&e)[Q], float (&mxl)[Q], float (&sm)[Q], float &l2s_all) const {
     float m[Q];
 #pragma unroll
     for (int f = 0; f < Q; ++f) {
-      m[f] = fmaxf(fmaxf(xr[f][0].x, xr[f][0].y), fmaxf(xr[f][0].z, xr[f][0].w));
+      m[f] = vmax_raw(vmax3_raw(xr[f][0].x, xr[f][0].y, xr[f][0].z), xr[f][0].w);
 #pragma unroll
-      for (int q = 1; q < VPL; ++q) m[f] = fmaxf(m[f], fmaxf(fmaxf(xr[f][q].x, xr[f][q].y), fmaxf(xr[f][q].z, xr[f][q].w)));
+      for (int q = 1; q < VPL; ++q) m[f] = vmax3_raw(vmax3_raw(m[f], xr[f][q].x, xr[f][q].y), xr[f][q].z, xr[f][q].w);
     }
     constexpr bool SWAP = (Q == 2 || Q == 4);  // (ctc_swap_reduce.h: all Q values through one register)
     float mall = 0.f;
     if constexpr (SWAP) mall = swap_reduce<Q, true>(m);
     else dpp_max_n<Q>(m);
     float4 ev[Q][VPL];
-    float sm[Q];
+    float part[Q];
 #pragma unroll
     for (int f = 0; f < Q; ++f) {
       float mx;
@@ -541,21 +552,21 @@ struct Rows {
       mx = (mx == -INFINITY) ? 0.f : mx;
       mxl[f] = mx * LOG2E;
       expo(xr[f], mxl[f], ev[f]);
-      sm[f] = 0.f;
+      part[f] = (ev[f][0].x + ev[f][0].y) + (ev[f][0].z + ev[f][0].w);
 #pragma unroll
-      for (int q = 0; q < VPL; ++q) sm[f] += (ev[f][q].x + ev[f][q].y) + (ev[f][q].z + ev[f][q].w);
+      for (int q = 1; q < VPL; ++q) part[f] += (ev[f][q].x + ev[f][q].y) + (ev[f][q].z + ev[f][q].w);
     }
     float sall = 0.f;
-    if constexpr (SWAP) sall = swap_reduce<Q, false>(sm);
-    else dpp_sum_n<Q>(sm);
+    if constexpr (SWAP) sall = swap_reduce<Q, false>(part);
+    else dpp_sum_n<Q>(part);
+    float prod = 1.f;
 #pragma unroll
     for (int f = 0; f < Q; ++f) {
-      float s;
-      if constexpr (SWAP) s = readlane_f(sall, SwapLanes<SWAP ? Q : 2>::lane(f));
-      else s = readlane_f(sm[f], 63);
-      l2s[f] = flog2(s);
-      inv[f] = __builtin_amdgcn_rcpf(s);
+      if constexpr (SWAP) sm[f] = readlane_f(sall, SwapLanes<SWAP ? Q : 2>::lane(f));
+      else sm[f] = readlane_f(part[f], 63);
+      prod = (f == 0) ? sm[0] : prod * sm[f];
     }
+    l2s_all = flog2(prod);
 #pragma unroll
     for (int f = 0; f < Q; ++f) gather(ev[f], e[f]);  // LDS operations of a wavefront execute in program order: one copy serves all
   }
@@ -660,11 +671,10 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL, VPL, XT> &S, Lds<KI
   float zmin[NL], zb = 1.0f;
 #pragma unroll
   for (int j = 0; j < NL; ++j) zmin[j] = 1.0f;
-  auto track = [&](const Emis<NL> &e, float l2s) __attribute__((always_inline)) {
+  auto track = [&](const Emis<NL> &e) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < NL; ++j) zmin[j] = fminf(zmin[j], e.y[j]);
-    zb = fminf(zb, e.bl);
-    acc += (double)l2s;
+    for (int j = 0; j < NL; ++j) zmin[j] = vmin_raw(zmin[j], e.y[j]);
+    zb = vmin_raw(zb, e.bl);
   };
   // FAST: steady state -- the block exists and is full, so the body has NO branch around a memory operation.  hipcc derives
   // `s_waitcnt vmcnt(N)` from the fewest memory operations any path can have issued after the load it waits for; with a
@@ -679,12 +689,12 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL, VPL, XT> &S, Lds<KI
       const int g = geo.absblock(1, SIDE, j);
       const int nv = FAST ? BLK : geo.nvof(g);
       float(*E)[LD::ES] = lds.E[SIDE][j % 3];
-      float smx = 0.f, sinv = 0.f;  // lane d keeps the statistics of position d of the block
+      float smx = 0.f, ssum = 1.f;  // lane d keeps the statistics of position d of the block (its sum; ONE reciprocal below)
       if (FAST || nv == BLK) {
         if constexpr (NQ > 0) {
           float4 xq[NQA][VPL];
           Emis<NL> e[NQA];
-          float mxl[NQA], inv[NQA], l2s[NQA];
+          float mxl[NQA], sm[NQA], l2s;
           static_for<0, NQA>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             static_for<0, VPL>([&](auto W) {
@@ -692,13 +702,14 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL, VPL, XT> &S, Lds<KI
               xq[q][w] = make_float4(xb[r][q][w].x, xb[r][q][w].y, xb[r][q][w].z, xb[r][q][w].w);
             });
           });
-          S.template emit_n<NQA>(xq, e, mxl, inv, l2s);
+          S.template emit_n<NQA>(xq, e, mxl, sm, l2s);
+          acc += (double)l2s;
           static_for<0, NQA>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             write_E(E[P0 + q], e[q]);
-            track(e[q], l2s[q]);
+            track(e[q]);
             smx = (lane == P0 + q) ? mxl[q] : smx;
-            sinv = (lane == P0 + q) ? inv[q] : sinv;
+            ssum = (lane == P0 + q) ? sm[q] : ssum;
           });
         }
       } else {
@@ -708,12 +719,13 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL, VPL, XT> &S, Lds<KI
             float4 xr[1][VPL];
             S.io.load_x(xr[0], geo.frame(SIDE, g, d));
             Emis<NL> e[1];
-            float mxl[1], inv[1], l2s[1];
-            S.template emit_n<1>(xr, e, mxl, inv, l2s);
+            float mxl[1], sm[1], l2s;
+            S.template emit_n<1>(xr, e, mxl, sm, l2s);
+            acc += (double)l2s;
             write_E(E[d], e[0]);
-            track(e[0], l2s[0]);
+            track(e[0]);
             smx = (lane == d) ? mxl[0] : smx;
-            sinv = (lane == d) ? inv[0] : sinv;
+            ssum = (lane == d) ? sm[0] : ssum;
           }
         }
       }
@@ -723,7 +735,7 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL, VPL, XT> &S, Lds<KI
       });
       const bool mine = lane >= P0 && lane < P0 + NQ && lane < nv;
       float2 *dst = mine ? stats + geo.frame(SIDE, g, mine ? lane : 0) : sink;  // unconditional store: no branch
-      *dst = make_float2(smx, sinv);
+      *dst = make_float2(smx, __builtin_amdgcn_rcpf(ssum));  // 1 / sum exp of this lane's frame
     }
     F6_BARRIER();
   };
@@ -929,16 +941,22 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
         float(*KLr)[64] = lds.kl[DIR][j % 3];
         int q = -1, kR = DEAD, ks = DEAD, k0r = DEAD;
         float KL = 0.f, KS = 0.f, K0 = 0.f;
+        float PL = 1.f, PS = 1.f, P0 = 1.f;  // pre-scale of the chain's operand for the aligned / shifted / boundary products
+        bool wide = false;                   // wave-uniform: some lane's scale exceeds 2^KK_MAX in this exponent group
         auto setK = [&]() __attribute__((always_inline)) {
           const int ka = S.k + kR - lp_int, kb = S.k + ks - lp_int, kc = S.kx + k0r - lp_int;
-          // D5.  What it catches on benign inputs (1 utterance in 64 at T = 5000, classic): a lane whose two label positions
-          // differ by more than 2^90 in alpha and by as much the other way in beta -- the alignment is crossing between them --
-          // so both posteriors are O(1) products of a tiny and a big mantissa and the scale of the lane leaves float32.
-          // (Counting only lanes that had mass at their last renormalisation changes nothing: these lanes are alive.)
-          kflag |= (imax(ka, imax(kb, kc)) > KK_MAX);
+          const int kmx = imax(ka, imax(kb, kc));
+          // D5 proper: only beyond 2^KK_MAX2 (see KK_MAX)
+          kflag |= (kmx > KK_MAX2);
           KL = ldexp_f(cf30, imin(ka, KK_MAX));
           KS = ldexp_f(cf30, imin(kb, KK_MAX));
           K0 = ldexp_f(cf30, imin(kc, KK_MAX));
+          wide = __builtin_amdgcn_ballot_w64(kmx > KK_MAX) != 0;
+          if (wide) {
+            PL = ldexp_f(1.f, imin(imax(ka - KK_MAX, 0), KK_MAX2 - KK_MAX));
+            PS = ldexp_f(1.f, imin(imax(kb - KK_MAX, 0), KK_MAX2 - KK_MAX));
+            P0 = ldexp_f(1.f, imin(imax(kc - KK_MAX, 0), KK_MAX2 - KK_MAX));
+          }
         };
         auto one = [&](int d, int qd, bool ren, const Emis<NL> &e, const RRow<KIND, NL> &r, int kRq) __attribute__((always_inline)) {
           if (qd != q) {  // new exponent group of the rows (the boundary exponent r.kx is constant inside a group as well)
@@ -956,44 +974,69 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
             if constexpr (DIR == 0) S.step(e);  // A: posterior of frame t from alpha[t+1], beta[t+1]
             // (A renormalises after the products below; its exponent is still the one the scales were built from.  A mantissa
             // product may underflow -- by then it is below 2^-16 units after scaling -- but never overflows)
+            if (__builtin_expect(!wide, 1)) {
 #pragma unroll
-            for (int jj = 0; jj < NL; ++jj) tok[jj] = S.o[jj] * r.o[jj];
-            if constexpr (DIR == 0) {
+              for (int jj = 0; jj < NL; ++jj) tok[jj] = S.o[jj] * r.o[jj];
+              if constexpr (DIR == 0) {
 #pragma unroll
-              for (int jj = 0; jj < NL - 1; ++jj) qal += S.c[jj] * r.c[jj + 1];
-              qsh = (S.c[NL - 1] * rs) * KS;
-            } else {
+                for (int jj = 0; jj < NL - 1; ++jj) qal += S.c[jj] * r.c[jj + 1];
+                qsh = (S.c[NL - 1] * rs) * KS;
+              } else {
 #pragma unroll
-              for (int jj = 1; jj < NL; ++jj) qal += S.c[jj] * r.c[jj - 1];
-              qsh = (S.c[0] * rs) * KS;
+                for (int jj = 1; jj < NL; ++jj) qal += S.c[jj] * r.c[jj - 1];
+                qsh = (S.c[0] * rs) * KS;
+              }
+              p0 = S.cx * r0;
+            } else {  // the same products with the excess scale on this chain's operand first (KK_MAX)
+#pragma unroll
+              for (int jj = 0; jj < NL; ++jj) tok[jj] = (S.o[jj] * PL) * r.o[jj];
+              if constexpr (DIR == 0) {
+#pragma unroll
+                for (int jj = 0; jj < NL - 1; ++jj) qal += (S.c[jj] * PL) * r.c[jj + 1];
+                qsh = ((S.c[NL - 1] * PS) * rs) * KS;
+              } else {
+#pragma unroll
+                for (int jj = 1; jj < NL; ++jj) qal += (S.c[jj] * PL) * r.c[jj - 1];
+                qsh = ((S.c[0] * PS) * rs) * KS;
+              }
+              p0 = (S.cx * P0) * r0;
             }
-            p0 = S.cx * r0;
           } else if constexpr (DIR == 0) {
             const float pin0 = ldexp_f(from_prev_lane(S.c[NL - 1], S.cx), S.dk);
+            auto parts = [&](auto WIDEt) __attribute__((always_inline)) {
+              constexpr bool W = decltype(WIDEt)::value;  // W: excess scale on this chain's operand first (KK_MAX)
 #pragma unroll
-            for (int jj = 0; jj < NL; ++jj) {
-              const float pin = (jj == 0) ? pin0 : S.c[jj - 1];
-              const float rn = (jj < NL - 1) ? r.c[(jj + 1) % NL] : rs;  // b(l = i+1)
-              tok[jj] = (pin * e.y[jj]) * rn;
-              if (jj < NL - 1) qal += S.c[jj] * rn;
-            }
-            qal *= e.bl;
-            qsh = ((S.c[NL - 1] * rs) * e.bl) * KS;
-            tok[NL - 1] *= KS;
-            p0 = S.cx * e.bl * r0;
+              for (int jj = 0; jj < NL; ++jj) {
+                const float pin = (jj == 0) ? pin0 : S.c[jj - 1];
+                const float rn = (jj < NL - 1) ? r.c[(jj + 1) % NL] : rs;  // b(l = i+1)
+                const float pf = W ? pin * (jj < NL - 1 ? PL : PS) : pin;
+                tok[jj] = (pf * e.y[jj]) * rn;
+                if (jj < NL - 1) qal += (W ? S.c[jj] * PL : S.c[jj]) * rn;
+              }
+              qal *= e.bl;
+              qsh = (((W ? S.c[NL - 1] * PS : S.c[NL - 1]) * rs) * e.bl) * KS;
+              tok[NL - 1] *= KS;
+              p0 = (W ? S.cx * P0 : S.cx) * e.bl * r0;
+            };
+            if (__builtin_expect(!wide, 1)) parts(std::false_type{}); else parts(std::true_type{});
           } else {
             const float nin = ldexp_f(from_next_lane(S.c[0], S.cx), S.dk);
+            auto parts = [&](auto WIDEt) __attribute__((always_inline)) {
+              constexpr bool W = decltype(WIDEt)::value;
 #pragma unroll
-            for (int jj = 0; jj < NL; ++jj) {
-              const float nx = (jj == NL - 1) ? nin : S.c[(jj + 1) % NL];
-              const float rp = (jj > 0) ? r.c[(jj + NL - 1) % NL] : rs;  // a(l = i)
-              tok[jj] = (rp * e.y[jj]) * nx;
-              if (jj > 0) qal += S.c[jj] * rp;
-            }
-            qal *= e.bl;
-            qsh = ((S.c[0] * rs) * e.bl) * KS;
-            tok[0] *= KS;
-            p0 = S.cx * e.bl * r0;
+              for (int jj = 0; jj < NL; ++jj) {
+                const float nx = (jj == NL - 1) ? nin : S.c[(jj + 1) % NL];
+                const float rp = (jj > 0) ? r.c[(jj + NL - 1) % NL] : rs;  // a(l = i)
+                if constexpr (W) tok[jj] = ((nx * (jj > 0 ? PL : PS)) * e.y[jj]) * rp;  // (the pre-scaled operand first)
+                else tok[jj] = (rp * e.y[jj]) * nx;
+                if (jj > 0) qal += (W ? S.c[jj] * PL : S.c[jj]) * rp;
+              }
+              qal *= e.bl;
+              qsh = (((W ? S.c[0] * PS : S.c[0]) * rs) * e.bl) * KS;
+              tok[0] *= KS;
+              p0 = (W ? S.cx * P0 : S.cx) * e.bl * r0;
+            };
+            if (__builtin_expect(!wide, 1)) parts(std::false_type{}); else parts(std::true_type{});
           }
           qsh = (lane == 0) ? qsh + p0 * K0 : qsh;  // the boundary state (uniform) rides in lane 0's scaled part
           float *srow = RR[d] + 2 * lane * NL;

@@ -17,10 +17,13 @@
 // Pipeline: emit_kernel -> scan_kernel (values, ctc_kernels.hip) -> temit_kernel (tangent emissions) -> tscan_kernel
 // (tangent sweeps, one wavefront per utterance x direction, next step prefetched) -> hvp_out_kernel (wave per frame).
 #include "ctc_fused_common.h"
+#include "ctc_hvp_fused.h"
 
 namespace ctc {
 
 using namespace ctc::fused;
+
+dim3 sel_grid(int B, int T);  // ctc_kernels.hip: grid of the selected-utterance kernels
 
 // Extra workspace of the HVP (after Layout::off_extra): tangent emissions [B][T][ERS], tangent lattice rows
 // dalpha/dbeta [B][T+1][SRS] (same layouts as the value rows), dlogP [B].
@@ -39,18 +42,20 @@ static inline HvpLayout make_hvp_layout(const Layout &L, int B, int T) {
   return H;
 }
 size_t hvp_extra_bytes(int kind, int B, int T, int V, int U) {
-  (void)V;
+  Layout L = make_layout(kind, B, T, U, 0);
+  // (the fused kernel's region sits behind the log-domain pipeline's: the latter still serves the utterances the former flags)
+  return make_hvp_layout(L, B, T).total + (hvp_fused_shape(0, B, T, V, U) ? make_hvp_fused_layout(B, T, U).total : 0);
+}
+// offset of the fused kernel's region inside the extra part of the workspace
+size_t hvp_fused_offset(int kind, int B, int T, int U) {
   Layout L = make_layout(kind, B, T, U, 0);
   return make_hvp_layout(L, B, T).total;
 }
 
 // tangent emissions: dE[i] = u[label[i]] (0 beyond the label), [UP] = u[blank], [UP+1] = s . v (logits mode)
-__global__ __launch_bounds__(256) void temit_kernel(Problem p, Layout L, const float *__restrict__ emis,
-                                                     const float *__restrict__ vec, float *__restrict__ demis) {
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (row >= (long)p.B * p.T) return;
-  const int b = (int)(row / p.T), t = (int)(row % p.T);
+__device__ __forceinline__ void temit_row(const Problem &p, const Layout &L, const float *__restrict__ emis, const float *__restrict__ vec,
+                                          float *__restrict__ demis, int b, int t, int lane) {
+  const long row = (long)b * p.T + t;
   const int len = clampi(p.logit_length[b], 0, p.T);
   if (t >= len) return;
   const int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
@@ -88,15 +93,34 @@ __global__ __launch_bounds__(256) void temit_kernel(Problem p, Layout L, const f
   }
 }
 
+__global__ __launch_bounds__(256) void temit_kernel(Problem p, Layout L, const float *__restrict__ emis,
+                                                     const float *__restrict__ vec, float *__restrict__ demis) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (row >= (long)p.B * p.T) return;
+  temit_row(p, L, emis, vec, demis, (int)(row / p.T), (int)(row % p.T), lane);
+}
+// selected utterances only (ctc_kernels.hip emit_sel_kernel)
+__global__ __launch_bounds__(256) void temit_sel_kernel(Problem p, Layout L, const float *__restrict__ emis, const float *__restrict__ vec,
+                                                         float *__restrict__ demis, const int *__restrict__ only_if) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int b = blockIdx.y; b < p.B; b += gridDim.y) {
+    if (only_if[b] == 0) continue;
+    for (int t = blockIdx.x * 4 + w; t < p.T; t += gridDim.x * 4) temit_row(p, L, emis, vec, demis, b, t, lane);
+  }
+}
+
 // One wavefront per (utterance, direction): tangent sweep.  Slot/state conventions = Scan in ctc_kernels.hip.
 template <int KIND, int NL>
 __global__ __launch_bounds__(64) void tscan_kernel(Problem p, Layout L, const float *__restrict__ emis,
                                                     const float *__restrict__ demis, const float *__restrict__ alpha,
                                                     const float *__restrict__ beta, const double *__restrict__ logp,
                                                     float *__restrict__ dalpha, float *__restrict__ dbeta,
-                                                    float *__restrict__ dlogp) {
+                                                    float *__restrict__ dlogp, const int *__restrict__ only_if) {
   const int lane = threadIdx.x;
   const int b = blockIdx.x, dir = blockIdx.y;
+  if (only_if && only_if[b] == 0) return;  // (selected utterances only)
   const int T = p.T, UP = L.UP;
   const int len = clampi(p.logit_length[b], 0, T);
   int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
@@ -325,18 +349,13 @@ __global__ __launch_bounds__(64) void tscan_kernel(Problem p, Layout L, const fl
 
 // One wavefront per frame: d(posterior) scattered by token, chain rule through log-softmax for logits.
 template <int KIND>
-__global__ __launch_bounds__(256) void hvp_out_kernel(Problem p, Layout L, const float *__restrict__ emis,
-                                                       const float *__restrict__ demis, const float *__restrict__ alpha,
-                                                       const float *__restrict__ beta, const float *__restrict__ dalpha,
-                                                       const float *__restrict__ dbeta, const double *__restrict__ logp,
-                                                       const float *__restrict__ dlogp, const float *__restrict__ vec,
-                                                       float *__restrict__ out, int wpb) {
-  extern __shared__ float lds[];
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps everything derived from it in SGPRs
-  const long row = (long)blockIdx.x * wpb + w;
-  if (row >= (long)p.B * p.T) return;
-  const int b = (int)(row / p.T), t = (int)(row % p.T);
+__device__ __forceinline__ void hvp_out_row(const Problem &p, const Layout &L, const float *__restrict__ emis,
+                                            const float *__restrict__ demis, const float *__restrict__ alpha,
+                                            const float *__restrict__ beta, const float *__restrict__ dalpha,
+                                            const float *__restrict__ dbeta, const double *__restrict__ logp,
+                                            const float *__restrict__ dlogp, const float *__restrict__ vec,
+                                            float *__restrict__ out, float *bin, int b, int t, int lane) {
+  const long row = (long)b * p.T + t;
   const int V = p.V, UP = L.UP;
   float *o = out + row * (long)V;
   const int len = clampi(p.logit_length[b], 0, p.T);
@@ -346,7 +365,6 @@ __global__ __launch_bounds__(256) void hvp_out_kernel(Problem p, Layout L, const
     for (int k = lane; k < V; k += 64) __builtin_nontemporal_store(0.f, o + k);  // the Hessian vanishes there (base_loss.py:240-258)
     return;
   }
-  float *bin = lds + (long)w * V;
   for (int k = lane; k < V; k += 64) bin[k] = 0.f;
   wave_lds_fence();
   constexpr int PAIR = (KIND == 0) ? 2 : 1;
@@ -414,16 +432,42 @@ __global__ __launch_bounds__(256) void hvp_out_kernel(Problem p, Layout L, const
 }
 
 template <int KIND>
+__global__ __launch_bounds__(256) void hvp_out_kernel(Problem p, Layout L, const float *__restrict__ emis,
+                                                       const float *__restrict__ demis, const float *__restrict__ alpha,
+                                                       const float *__restrict__ beta, const float *__restrict__ dalpha,
+                                                       const float *__restrict__ dbeta, const double *__restrict__ logp,
+                                                       const float *__restrict__ dlogp, const float *__restrict__ vec,
+                                                       float *__restrict__ out, int wpb, const int *__restrict__ only_if) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps everything derived from it in SGPRs
+  float *bin = lds + (long)w * p.V;
+  if (only_if) {  // selected utterances only: blockIdx.y strides over utterances, blockIdx.x over the frames of a selected one
+    for (int b = blockIdx.y; b < p.B; b += gridDim.y) {
+      if (only_if[b] == 0) continue;
+      for (int t = blockIdx.x * wpb + w; t < p.T; t += gridDim.x * wpb) {
+        hvp_out_row<KIND>(p, L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, bin, b, t, lane);
+        wave_lds_fence();  // the bins are reused by the next frame of this wavefront
+      }
+    }
+    return;
+  }
+  const long row = (long)blockIdx.x * wpb + w;
+  if (row >= (long)p.B * p.T) return;
+  hvp_out_row<KIND>(p, L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, bin, (int)(row / p.T), (int)(row % p.T), lane);
+}
+
+template <int KIND>
 static hipError_t launch_hvp(const Problem &p, const Layout &L, const float *emis, float *demis, const float *alpha,
                              const float *beta, float *dalpha, float *dbeta, const double *logp, float *dlogp,
-                             const float *vec, float *out, hipStream_t st) {
+                             const float *vec, float *out, const int *only_if, hipStream_t st) {
   dim3 grid(p.B, 2), block(64);
   switch (L.NL) {
-    case 1: hipLaunchKernelGGL((tscan_kernel<KIND, 1>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp); break;
-    case 2: hipLaunchKernelGGL((tscan_kernel<KIND, 2>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp); break;
-    case 4: hipLaunchKernelGGL((tscan_kernel<KIND, 4>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp); break;
-    case 8: hipLaunchKernelGGL((tscan_kernel<KIND, 8>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp); break;
-    case 16: hipLaunchKernelGGL((tscan_kernel<KIND, 16>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp); break;
+    case 1: hipLaunchKernelGGL((tscan_kernel<KIND, 1>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp, only_if); break;
+    case 2: hipLaunchKernelGGL((tscan_kernel<KIND, 2>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp, only_if); break;
+    case 4: hipLaunchKernelGGL((tscan_kernel<KIND, 4>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp, only_if); break;
+    case 8: hipLaunchKernelGGL((tscan_kernel<KIND, 8>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp, only_if); break;
+    case 16: hipLaunchKernelGGL((tscan_kernel<KIND, 16>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp, only_if); break;
     default: return hipErrorInvalidValue;
   }
   hipError_t e = hipGetLastError();
@@ -431,13 +475,15 @@ static hipError_t launch_hvp(const Problem &p, const Layout &L, const float *emi
   const long rows = (long)p.B * p.T;
   int wpb = 4;
   while (wpb > 1 && (size_t)wpb * p.V * 4 > 64 * 1024) wpb >>= 1;
-  hipLaunchKernelGGL(hvp_out_kernel<KIND>, dim3((unsigned)((rows + wpb - 1) / wpb)), dim3(64 * wpb), (size_t)wpb * p.V * 4, st, p,
-                     L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, wpb);
+  const dim3 ogrid = only_if ? sel_grid(p.B, p.T) : dim3((unsigned)((rows + wpb - 1) / wpb));
+  hipLaunchKernelGGL(hvp_out_kernel<KIND>, ogrid, dim3(64 * wpb), (size_t)wpb * p.V * 4, st, p,
+                     L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, wpb, only_if);
   return hipGetLastError();
 }
 
-// values must already be in the workspace (run_emit_scan with both directions)
-hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec, float *out, hipStream_t st) {
+// values must already be in the workspace (run_emit_scan with both directions); only_if != NULL: the utterances with a non-zero
+// entry only (those the fused kernel flagged), everything else of `out` is left alone
+hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec, float *out, hipStream_t st, const int *only_if) {
   const long rows = (long)p.B * p.T;
   if (rows == 0) return hipSuccess;
   const HvpLayout H = make_hvp_layout(L, p.B, p.T);
@@ -451,11 +497,12 @@ hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec
   float *dbeta = reinterpret_cast<float *>(ex + H.off_dbeta);
   float *dlogp = reinterpret_cast<float *>(ex + H.off_dlogp);
   // (four rows per wavefront, as emit4_kernel does, was tried here and lost: 195 against 172 us at the north-star shape)
-  hipLaunchKernelGGL(temit_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, L, emis, vec, demis);
+  if (only_if) hipLaunchKernelGGL(temit_sel_kernel, sel_grid(p.B, p.T), dim3(256), 0, st, p, L, emis, vec, demis, only_if);
+  else hipLaunchKernelGGL(temit_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, L, emis, vec, demis);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return p.kind == 0 ? launch_hvp<0>(p, L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, st)
-                     : launch_hvp<1>(p, L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, st);
+  return p.kind == 0 ? launch_hvp<0>(p, L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, only_if, st)
+                     : launch_hvp<1>(p, L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, only_if, st);
 }
 
 }  // namespace ctc

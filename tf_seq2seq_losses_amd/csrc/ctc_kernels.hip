@@ -23,11 +23,9 @@ __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? l
 // ------------------------------------------------------------------------------------------------
 // emit
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void emit_kernel(Problem p, Layout L, float *__restrict__ emis) {
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (row >= (long)p.B * p.T) return;
-  const int b = (int)(row / p.T), t = (int)(row % p.T);
+// one frame (b, t) by one wavefront
+__device__ __forceinline__ void emit_row(const Problem &p, const Layout &L, float *__restrict__ emis, int b, int t, int lane) {
+  const long row = (long)b * p.T + t;
   const int len = clampi(p.logit_length[b], 0, p.T);
   if (t >= len) return;  // padded frames are never read downstream
   const int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
@@ -103,6 +101,24 @@ __global__ __launch_bounds__(256) void emit_kernel(Problem p, Layout L, float *_
     erow[L.UP + 1] = mx;
     erow[L.UP + 2] = log2sum;
     erow[L.UP + 3] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void emit_kernel(Problem p, Layout L, float *__restrict__ emis) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (row >= (long)p.B * p.T) return;
+  emit_row(p, L, emis, (int)(row / p.T), (int)(row % p.T), lane);
+}
+// The frames of SELECTED utterances only (only_if[b] != 0: the utterances a fused kernel flagged for the log-domain pipeline,
+// normally none).  A small fixed grid walks the batch -- blockIdx.y strides over utterances, blockIdx.x over the frames of a
+// selected one -- so a call that selects nothing costs 2 048 workgroups that read 32 flags each, not B T / 4 empty ones.
+__global__ __launch_bounds__(256) void emit_sel_kernel(Problem p, Layout L, float *__restrict__ emis, const int *__restrict__ only_if) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int b = blockIdx.y; b < p.B; b += gridDim.y) {
+    if (only_if[b] == 0) continue;
+    for (int t = blockIdx.x * 4 + w; t < p.T; t += gridDim.x * 4) emit_row(p, L, emis, b, t, lane);
   }
 }
 
@@ -604,6 +620,131 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// log posterior (logarithmic_logproba_gradient, base_loss.py:270-298): lg[b,t,k] = log P(frame t emits k | label), computed
+// in the LOG domain end to end -- a posterior of e^-150 comes out as -150, where log(-gradient) of the float32 gradient
+// gives -inf below e^-87.  Per frame (one wavefront): q_i = alpha + beta + offsets - log P per lattice state (base-2 logs,
+// summed in double like grad_kernel), then the segment log-sum-exp by token (tools.py:74-119) in two LDS passes: the
+// per-token maximum by an integer atomic max on an order-preserving key, then sum 2^(q_i - max) in fixed point (units of
+// 2^-20: up to 1024 states of one token; the maximum itself contributes exactly 1, so the sum is never 0).
+// Frames beyond logit_length, infeasible samples and tokens that no state emits: -inf (base_loss.py:283-298).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int order_key(float x) { const int b = __float_as_int(x); return b ^ ((b >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float key_value(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+
+template <int KIND>
+__global__ __launch_bounds__(256) void logpost_kernel(Problem p, Layout L, const float *__restrict__ emis,
+                                                       const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                       const double *__restrict__ logp, float *__restrict__ out, int waves_per_block) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long row = (long)blockIdx.x * waves_per_block + w;
+  if (row >= (long)p.B * p.T) return;
+  const int b = (int)(row / p.T), t = (int)(row % p.T);
+  const int V = p.V, UP = L.UP;
+  float *o = out + row * (long)V;
+  const int len = clampi(p.logit_length[b], 0, p.T);
+  const double lp = logp[b];
+  int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  if (t >= len || lp == -INFINITY || ll > p.U) {
+    for (int k = lane; k < V; k += 64) o[k] = -INFINITY;
+    return;
+  }
+  int *kmax = reinterpret_cast<int *>(lds) + (long)w * 2 * V;
+  unsigned *ksum = reinterpret_cast<unsigned *>(kmax + V);
+  const int KEY_NONE = order_key(-3.0e38f);
+  for (int k = lane; k < V; k += 64) { kmax[k] = KEY_NONE; ksum[k] = 0u; }
+  wave_lds_fence();
+  const int32_t *lab = p.labels + (long)b * p.label_stride;
+  const float *ra = alpha + ((long)b * (p.T + 1) + (KIND == 0 ? t + 1 : t)) * L.SRS;
+  const float *rb = beta + ((long)b * (p.T + 1) + t + 1) * L.SRS;
+  const int offpos = (KIND == 0 ? 2 * UP : UP) + 2;
+  const double scale = (double)ra[offpos] + (double)ra[offpos + 1] + (double)rb[offpos] + (double)rb[offpos + 1] - lp;
+  // log2 posterior of one state; "impossible" stays at the finite sentinel scale (< NEG_THR)
+  auto lq = [&](float a_, float b_) -> float { return (a_ < NEG_THR || b_ < NEG_THR) ? NEG : (float)((double)a_ + (double)b_ + scale); };
+  auto lq3 = [&](float a_, float b_, float c_) -> float {
+    return (a_ < NEG_THR || b_ < NEG_THR || c_ < NEG_THR) ? NEG : (float)((double)a_ + (double)b_ + (double)c_ + scale);
+  };
+  constexpr int MAXI = CTC_AMD_MAX_U / 64;  // label positions per lane at most
+  float qtok[MAXI], qbl[MAXI];
+  float q0 = NEG;  // the boundary state (lane 0)
+  const float *er = emis + row * (long)L.ERS;
+  const float bl = (KIND == 1) ? er[UP] : 0.f;
+#pragma unroll
+  for (int n = 0; n < MAXI; ++n) {
+    const int i = lane + 64 * n;
+    qtok[n] = NEG; qbl[n] = NEG;
+    if (i < UP) {
+      if constexpr (KIND == 0) {
+        const float2 a = *reinterpret_cast<const float2 *>(ra + 2 * i), bb = *reinterpret_cast<const float2 *>(rb + 2 * i);
+        qbl[n] = lq(a.x, bb.x);
+        if (i < ll) qtok[n] = lq(a.y, bb.y);
+      } else {
+        const float ai = ra[i], bi = rb[i];
+        qbl[n] = lq3(ai, bi, bl);
+        if (i < ll) qtok[n] = lq3((i == 0) ? ra[UP] : ra[i - 1], er[i], bi);
+      }
+    }
+  }
+  if (lane == 0) q0 = (KIND == 0) ? lq(ra[2 * UP], rb[2 * UP]) : lq3(ra[UP], rb[UP], bl);
+  // pass 1: per-token maximum
+#pragma unroll
+  for (int n = 0; n < MAXI; ++n) {
+    const int i = lane + 64 * n;
+    if (i < ll && qtok[n] > NEG_THR) {
+      const int tok = (i < p.label_stride) ? lab[i] : p.blank;
+      if (tok >= 0 && tok < V && tok != p.blank) atomicMax(&kmax[tok], order_key(qtok[n]));
+    }
+  }
+  wave_lds_fence();
+  // pass 2: sum of 2^(q - max) per token, fixed point
+#pragma unroll
+  for (int n = 0; n < MAXI; ++n) {
+    const int i = lane + 64 * n;
+    if (i < ll && qtok[n] > NEG_THR) {
+      const int tok = (i < p.label_stride) ? lab[i] : p.blank;
+      if (tok >= 0 && tok < V && tok != p.blank) {
+        const float mx = key_value(kmax[tok]);
+        atomicAdd(&ksum[tok], (unsigned)(fexp2(qtok[n] - mx) * 1048576.0f + 0.5f));
+      }
+    }
+  }
+  // blank: log-sum-exp over every closed state, in registers
+  float m = q0;
+#pragma unroll
+  for (int n = 0; n < MAXI; ++n) m = fmaxf(m, qbl[n]);
+  m = wave_max(m);
+  float sb = (q0 > NEG_THR) ? fexp2(q0 - m) : 0.f;
+#pragma unroll
+  for (int n = 0; n < MAXI; ++n) sb += (qbl[n] > NEG_THR) ? fexp2(qbl[n] - m) : 0.f;
+  sb = wave_sum(sb);
+  const float lblank = (m > NEG_THR && sb > 0.f) ? (m + flog2(sb)) * (float)LN2_D : -INFINITY;
+  wave_lds_fence();
+  for (int k = lane; k < V; k += 64) {
+    const unsigned su = ksum[k];
+    float v = (su > 0u) ? (key_value(kmax[k]) + flog2((float)su * 9.5367431640625e-7f)) * (float)LN2_D : -INFINITY;
+    if (k == p.blank) v = lblank;
+    o[k] = v;
+  }
+}
+
+hipError_t run_log_posterior(const Problem &p, const Layout &L, char *ws, float *out, hipStream_t st) {
+  const long rows = (long)p.B * p.T;
+  if (rows == 0) return hipSuccess;
+  const float *emis = reinterpret_cast<const float *>(ws + L.off_emis);
+  const float *alpha = reinterpret_cast<const float *>(ws + L.off_alpha);
+  const float *beta = reinterpret_cast<const float *>(ws + L.off_beta);
+  const double *logp = reinterpret_cast<const double *>(ws + L.off_logp);
+  int wpb = 4;
+  while (wpb > 1 && (size_t)wpb * p.V * 8 > 64 * 1024) wpb >>= 1;
+  const dim3 grid((unsigned)((rows + wpb - 1) / wpb)), block(64 * wpb);
+  const size_t shmem = (size_t)wpb * p.V * 8;
+  if (p.kind == 0) hipLaunchKernelGGL(logpost_kernel<0>, grid, block, shmem, st, p, L, emis, alpha, beta, logp, out, wpb);
+  else hipLaunchKernelGGL(logpost_kernel<1>, grid, block, shmem, st, p, L, emis, alpha, beta, logp, out, wpb);
+  return hipGetLastError();
+}
+
 // Wide vocabularies (V > 1024, float32 rows, 16-byte aligned): the same gradient with the vocabulary walked in passes of
 // 1024 columns.  The posterior of every label position is computed ONCE into a per-wavefront table (fixed point); each
 // pass zeroes a 4 KB bin array, adds the positions whose token falls into it, and streams its 1024 columns (logits in,
@@ -771,32 +912,39 @@ namespace ctc {
 template <int KIND, int NL>
 __global__ __launch_bounds__(64) void scan_kernel(Problem p, Layout L, const float *__restrict__ emis,
                                                    float *__restrict__ alpha, float *__restrict__ beta,
-                                                   double *__restrict__ logp, float *__restrict__ loss) {
+                                                   double *__restrict__ logp, float *__restrict__ loss, const int *__restrict__ only_if) {
+  if (only_if && only_if[blockIdx.x] == 0) return;  // (selected utterances only: see emit_sel_kernel)
   if (blockIdx.y == 0) scan_body<KIND, NL, 0>(p, L, emis, alpha, logp, loss);
   else scan_body<KIND, NL, 1>(p, L, emis, beta, logp, loss);
 }
 
 template <int KIND, int NL>
 static void launch_scan_nl(const Problem &p, const Layout &L, const float *emis, float *alpha, float *beta, double *logp,
-                           float *loss, int ndir, hipStream_t st) {
-  hipLaunchKernelGGL((scan_kernel<KIND, NL>), dim3(p.B, ndir), dim3(64), 0, st, p, L, emis, alpha, beta, logp, loss);
+                           float *loss, int ndir, const int *only_if, hipStream_t st) {
+  hipLaunchKernelGGL((scan_kernel<KIND, NL>), dim3(p.B, ndir), dim3(64), 0, st, p, L, emis, alpha, beta, logp, loss, only_if);
 }
 
 template <int KIND>
 static hipError_t launch_scan(const Problem &p, const Layout &L, const float *emis, float *alpha, float *beta,
-                              double *logp, float *loss, int ndir, hipStream_t st) {
+                              double *logp, float *loss, int ndir, const int *only_if, hipStream_t st) {
   switch (L.NL) {
-    case 1: launch_scan_nl<KIND, 1>(p, L, emis, alpha, beta, logp, loss, ndir, st); break;
-    case 2: launch_scan_nl<KIND, 2>(p, L, emis, alpha, beta, logp, loss, ndir, st); break;
-    case 4: launch_scan_nl<KIND, 4>(p, L, emis, alpha, beta, logp, loss, ndir, st); break;
-    case 8: launch_scan_nl<KIND, 8>(p, L, emis, alpha, beta, logp, loss, ndir, st); break;
-    case 16: launch_scan_nl<KIND, 16>(p, L, emis, alpha, beta, logp, loss, ndir, st); break;
+    case 1: launch_scan_nl<KIND, 1>(p, L, emis, alpha, beta, logp, loss, ndir, only_if, st); break;
+    case 2: launch_scan_nl<KIND, 2>(p, L, emis, alpha, beta, logp, loss, ndir, only_if, st); break;
+    case 4: launch_scan_nl<KIND, 4>(p, L, emis, alpha, beta, logp, loss, ndir, only_if, st); break;
+    case 8: launch_scan_nl<KIND, 8>(p, L, emis, alpha, beta, logp, loss, ndir, only_if, st); break;
+    case 16: launch_scan_nl<KIND, 16>(p, L, emis, alpha, beta, logp, loss, ndir, only_if, st); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *loss, int ndir, hipStream_t st) {
+// grid of the selected-utterance kernels: frames along x, utterances strided along y
+dim3 sel_grid(int B, int T) {
+  const int gx = (T + 3) / 4 < 256 ? (T + 3) / 4 : 256;
+  return dim3(gx < 1 ? 1 : gx, B < 8 ? (B < 1 ? 1 : B) : 8);
+}
+
+hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *loss, int ndir, hipStream_t st, const int *only_if) {
   float *emis = reinterpret_cast<float *>(ws + L.off_emis);
   float *alpha = reinterpret_cast<float *>(ws + L.off_alpha);
   float *beta = reinterpret_cast<float *>(ws + L.off_beta);
@@ -805,14 +953,15 @@ hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *los
   if (rows > 0) {
     const bool four = p.V <= 512 && p.xdtype == 0 && (p.align_bits & 15) == 0 && ((p.V | p.xsb | p.xst) & 3) == 0;
     const long waves = (long)p.B * ((p.T + 3) / 4);
-    if (four) hipLaunchKernelGGL(emit4_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, p, L, emis);
+    if (only_if) hipLaunchKernelGGL(emit_sel_kernel, sel_grid(p.B, p.T), dim3(256), 0, st, p, L, emis, only_if);
+    else if (four) hipLaunchKernelGGL(emit4_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, p, L, emis);
     else hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, L, emis);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
   if (p.B == 0) return hipSuccess;
-  return p.kind == 0 ? launch_scan<0>(p, L, emis, alpha, beta, logp, loss, ndir, st)
-                     : launch_scan<1>(p, L, emis, alpha, beta, logp, loss, ndir, st);
+  return p.kind == 0 ? launch_scan<0>(p, L, emis, alpha, beta, logp, loss, ndir, only_if, st)
+                     : launch_scan<1>(p, L, emis, alpha, beta, logp, loss, ndir, only_if, st);
 }
 
 hipError_t run_grad(const Problem &p, const Layout &L, char *ws, const float *d_loss, float *grad, hipStream_t st) {
@@ -938,17 +1087,23 @@ hipError_t run_reduce_loss(const float *loss, int B, float *out, hipStream_t st)
   return hipGetLastError();
 }
 
-// box probe of bench.py (ctc_amd_probe_copy): a plain streaming copy, 16 bytes per lane, four loads in flight, non-temporal stores
+// box probe of bench.py (ctc_amd_probe_copy): a plain streaming copy -- every workgroup owns one contiguous chunk, 16 bytes per
+// lane, eight loads in flight, non-temporal stores (the fastest of the copy shapes tried by scripts/r03_memprobe.hip: 5.7 TB/s
+// where a grid-stride copy with four loads in flight reached 4.6)
 __global__ __launch_bounds__(512) void probe_copy_kernel(float4 *__restrict__ dst, const float4 *__restrict__ src, long n) {
   typedef float v4f __attribute__((ext_vector_type(4)));
-  long i = (long)blockIdx.x * 512 + threadIdx.x;
-  const long stride = (long)gridDim.x * 512;
+  const long per = (n + gridDim.x - 1) / gridDim.x;
+  const long lo = per * blockIdx.x, hi = (lo + per < n) ? lo + per : n;
   auto put = [&](long k, float4 v) { v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(dst + k)); };
-  for (; i + 3 * stride < n; i += 4 * stride) {
-    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    put(i, a); put(i + stride, b); put(i + 2 * stride, c); put(i + 3 * stride, d);
+  long i = lo + threadIdx.x;
+  for (; i + 7 * 512 < hi; i += 8 * 512) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[i + u * 512];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) put(i + u * 512, v[u]);
   }
-  for (; i < n; i += stride) put(i, src[i]);
+  for (; i < hi; i += 512) put(i, src[i]);
 }
 // stand-in for a latency-bound collective kernel (ctc_amd_probe_spin): one workgroup, some LDS, polls the 100 MHz device clock.
 // Every wavefront reaches the exit: the loop ends on elapsed time, with a hard bound on the trip count.
@@ -968,7 +1123,7 @@ hipError_t run_probe_spin(int threads, int lds_bytes, float us, hipStream_t st) 
 }
 hipError_t run_probe_copy(void *dst, const void *src, size_t bytes, hipStream_t st) {
   if (bytes == 0) return hipSuccess;
-  hipLaunchKernelGGL(probe_copy_kernel, dim3(2048), dim3(512), 0, st, static_cast<float4 *>(dst), static_cast<const float4 *>(src), (long)(bytes / 16));
+  hipLaunchKernelGGL(probe_copy_kernel, dim3(8192), dim3(512), 0, st, static_cast<float4 *>(dst), static_cast<const float4 *>(src), (long)(bytes / 16));
   return hipGetLastError();
 }
 

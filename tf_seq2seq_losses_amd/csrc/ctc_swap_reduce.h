@@ -16,7 +16,7 @@ template <> struct SwapLanes<4> { static constexpr int lane(int f) { return f ==
 
 template <bool MAX>
 __device__ __forceinline__ float swap_op(float a, float b) {
-  if constexpr (MAX) return __builtin_fmaxf(a, b);
+  if constexpr (MAX) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }  // (no canonicalisation: ctc_common.h vmax_raw)
   else return a + b;
 }
 template <bool MAX>

@@ -255,8 +255,10 @@ class BaseCtcLossData:
 
     @cached_property
     def logarithmic_logproba_gradient(self) -> torch.Tensor:
-        """log(-gradient), -inf on padded frames and infeasible samples (base_loss.py:270-298)"""
-        return torch.log(-self.gradient)
+        """log of the posterior = log(-gradient), computed in log space like the reference does (base_loss.py:270-298): finite
+        where the float32 gradient underflows (e^-150 comes out as -150); -inf on padded frames, for infeasible samples and
+        for tokens no lattice state emits."""
+        return ops.log_posterior(self._kind, _lib.WRT_LOGPROBS, self._prep())[1]
 
     @cached_property
     def _alpha_beta(self):

@@ -13,16 +13,20 @@ KINDS = {"classic": _lib.CLASSIC, "simplified": _lib.SIMPLIFIED}
 # (two positions per lane) whatever the width says; beyond, every doubling selects a slower tier (four / eight positions per
 # lane, then the three-kernel pipeline) although the labels inside may be short (tests/common.py:89-94 pads labels to T).
 WIDTH_WORTH_A_LOOK = 128
-_MAXLEN_CACHE = {}  # (data_ptr, version, numel, device) of a label_length tensor -> its maximum (one sync per distinct tensor)
+_MAXLEN_CACHE = {}  # id(label_length tensor) -> (weak reference to it, its version, its maximum): one sync per distinct tensor
 
 
 def _device_max_label_length(t: torch.Tensor) -> int:
-    key = (t.data_ptr(), t._version, t.numel(), t.device)
-    m = _MAXLEN_CACHE.get(key)
-    if m is None:
-        if len(_MAXLEN_CACHE) > 64:
-            _MAXLEN_CACHE.clear()
-        m = _MAXLEN_CACHE[key] = int(t.max().item())  # device -> host sync, once per tensor (pass max_label_length= to avoid it)
+    """max(label_length) of a device tensor, fetched once per tensor OBJECT and version (a data pointer is no identity: the
+    caching allocator hands the same address to the next batch's tensor)."""
+    import weakref
+    hit = _MAXLEN_CACHE.get(id(t))
+    if hit is not None and hit[0]() is t and hit[1] == t._version:
+        return hit[2]
+    if len(_MAXLEN_CACHE) > 64:
+        _MAXLEN_CACHE.clear()
+    m = int(t.max().item())  # device -> host sync (pass max_label_length= to avoid it)
+    _MAXLEN_CACHE[id(t)] = (weakref.ref(t), t._version, m)
     return m
 
 
@@ -282,6 +286,21 @@ def alpha_beta(kind: int, wrt: int, p: Prepared):
                                     ws.data_ptr(), ws.numel(), _stream(p.device))
     _lib.check(rc, "ctc_amd_alpha_beta")
     return loss, alpha, beta
+
+
+def log_posterior(kind: int, wrt: int, p: Prepared):
+    """(loss[B], lg[B,T,V]): natural log of the posterior of "frame t emits token k", in log space (ctc_amd_log_posterior)."""
+    lib = _lib.load()
+    p = p.plain()
+    loss = torch.empty(p.B, dtype=torch.float32, device=p.device)
+    lg = torch.empty((p.B, p.T, p.V), dtype=torch.float32, device=p.device)
+    if p.B == 0:
+        return loss, lg
+    ws = _workspace(_lib.WS_ALPHA_BETA, kind, p)
+    with _on_device(p.device):
+        rc = lib.ctc_amd_log_posterior(*p.common(kind, wrt), _ptr(loss), _ptr(lg), ws.data_ptr(), ws.numel(), _stream(p.device))
+    _lib.check(rc, "ctc_amd_log_posterior")
+    return loss, lg
 
 
 def hessian(kind: int, wrt: int, p: Prepared, want_grad: bool = True):
