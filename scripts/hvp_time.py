@@ -1,18 +1,27 @@
-"""Diagnostic: Hessian-vector product time at the north-star shape (and the loss+grad call beside it)."""
-import os, sys, time
+"""Diagnostic: Hessian-vector product at the north-star shape -- device time per call (HIP events around runs of 4 calls) of the
+fused kernel + its (empty) fallback launches, of the log-domain pipeline, and of the fused kernel's timing modes (ctc_hvp_fused.hip
+`mode`: 1 = phase 1 only, 2 = helpers alone in phase 2, 4 = chains alone in phase 2; results are meaningless in those)."""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from tf_seq2seq_losses_amd import _lib, ops
-B, T, U, V = 256, 1000, 128, 256
+B, T, U, V = int(os.environ.get("F6_B", "256")), 1000, 128, 256
 host, dev = bench.make_inputs(B, T, U, V, 0, False, torch.device("cuda:0"))
-prep = ops.Prepared(dev["labels"], dev["logits"], dev["label_length"], dev["logit_length"], 0, U=U)
 v = torch.randn((B, T, V), device="cuda:0")
-for _ in range(3):
-    ops.hvp(0, _lib.WRT_LOGITS, prep, v)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(10):
-    ops.hvp(0, _lib.WRT_LOGITS, prep, v)
-torch.cuda.synchronize()
-print(f"hvp B={B} T={T} U={U} V={V}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms per call")
+
+
+def timed(kind, label):
+    prep = ops.Prepared(dev["labels"], dev["logits"], dev["label_length"], dev["logit_length"], 0, U=U)
+    fn = lambda: ops.hvp(kind, _lib.WRT_LOGITS, prep, v)
+    bench.prewarm(fn, 60.0)
+    ms, _ = bench._events_ms(fn, 40, 4)
+    print(f"{label:58s} {ms * 1e3:8.1f} us per call", flush=True)
+
+
+for kind, kn in ((0, "classic"), (1, "simplified")):
+    for mode, what in (("", "fused kernel + fallback launches"), ("v1", "log-domain pipeline (five launches)"), ("diag1", "fused, phase 1 only"),
+                       ("diag2", "fused, phase 2 with the helpers alone"), ("diag4", "fused, phase 2 with the chains alone")):
+        _lib.debug_override("hvp", mode)
+        timed(kind, f"{kn}: {what}")
+    _lib.debug_override("hvp", "")

@@ -9,7 +9,7 @@
 #include "ctc_hvp_fused.h"
 
 namespace ctc {
-hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *loss, int ndir, hipStream_t st, const int *only_if = nullptr);
+hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *loss, int ndir, hipStream_t st);
 hipError_t run_grad(const Problem &p, const Layout &L, char *ws, const float *d_loss, float *grad, hipStream_t st);
 hipError_t run_sum_loss_fixed(const float *loss, int B, long long *acc, long long *zero_next, hipStream_t st);
 hipError_t run_log_posterior(const Problem &p, const Layout &L, char *ws, float *out, hipStream_t st);
@@ -73,10 +73,10 @@ size_t hvp_extra_bytes(int kind, int B, int T, int V, int U);
 int g_force_pipeline = 0;      // 0 = best eligible tier, 1 = v1, 2 = fused2, 5 = fused5 (log domain)
 int g_force_hessian_slab = 0;  // 1 = the general one-slab-per-wavefront Hessian kernel also for short labels
 int g_force_hvp_v1 = 0;        // 1 = the log-domain Hessian-vector pipeline also where the fused kernel applies
-hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec, float *out, hipStream_t st, const int *only_if = nullptr);
-hipError_t run_hvp_fused_classic(const Problem &p, char *ws_fused, const float *vec, float *loss, float *out, hipStream_t st);
-hipError_t run_hvp_fused_simplified(const Problem &p, char *ws_fused, const float *vec, float *loss, float *out, hipStream_t st);
-size_t hvp_fused_offset(int kind, int B, int T, int U);
+int g_hvp_diag = 0;            // timing diagnostics of the fused kernel (ctc_hvp_fused.hip `mode`; results are then meaningless)
+hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec, float *out, hipStream_t st);
+hipError_t run_hvp_fused_classic(const Problem &p, const Layout &L, char *ws, const float *vec, float *loss, float *out, int mode, hipStream_t st);
+hipError_t run_hvp_fused_simplified(const Problem &p, const Layout &L, char *ws, const float *vec, float *loss, float *out, int mode, hipStream_t st);
 hipError_t run_reduce_loss(const float *loss, int B, float *out, hipStream_t st);
 hipError_t run_probe_copy(void *dst, const void *src, size_t bytes, hipStream_t st);
 hipError_t run_probe_spin(int threads, int lds_bytes, float us, hipStream_t st);
@@ -175,8 +175,14 @@ int ctc_amd_debug_override(const char *key, const char *value) {
     return CTC_AMD_OK;
   }
   if (!strcmp(key, "hvp")) {
+    if (!strncmp(value, "diag", 4) && value[4] >= '0' && value[4] <= '7' && !value[5]) {  // timing diagnostics (scripts/hvp_time.py)
+      ctc::g_hvp_diag = value[4] - '0';
+      ctc::g_force_hvp_v1 = 0;
+      return CTC_AMD_OK;
+    }
     if (strcmp(value, "") && strcmp(value, "v1")) return fail(CTC_AMD_EINVAL, "hvp override must be \"\" or \"v1\", got \"%s\"", value);
     ctc::g_force_hvp_v1 = !strcmp(value, "v1");
+    ctc::g_hvp_diag = 0;
     return CTC_AMD_OK;
   }
   return fail(CTC_AMD_EINVAL, "unknown override key \"%s\"", key);
@@ -468,22 +474,21 @@ int ctc_amd_hvp(int kind, int wrt, const float *logits, const int32_t *labels, i
   ctc::Problem p = make_problem(kind, wrt, logits, labels, label_stride, label_length, logit_length, blank_index, B, T, V, U);
   hipStream_t st = static_cast<hipStream_t>(stream);
   char *ws = static_cast<char *>(workspace);
-  // The fused linear-domain kernel (ctc_hvp_fused.hip) where its instantiations apply; it leaves a flag per utterance, and the
-  // log-domain pipeline below then runs for the flagged ones only (normally none: five launches that find nothing to do).
-  const int *only_if = nullptr;
+  // The fused linear-domain kernel (ctc_hvp_fused.hip) where its instantiations apply: ONE launch; utterances its number format
+  // cannot hold are redone by their own workgroup with the log-domain building blocks, inside the same launch.
   if (!grad && !ctc::g_force_hvp_v1 && ctc::hvp_fused_shape(wrt, B, T, V, U)) {
-    char *wsf = ws + L.off_extra + ctc::hvp_fused_offset(kind, B, T, U);
-    hipError_t ef = kind == 0 ? ctc::run_hvp_fused_classic(p, wsf, vec, loss, out, st) : ctc::run_hvp_fused_simplified(p, wsf, vec, loss, out, st);
+    hipError_t ef = kind == 0 ? ctc::run_hvp_fused_classic(p, L, ws, vec, loss, out, ctc::g_hvp_diag, st)
+                              : ctc::run_hvp_fused_simplified(p, L, ws, vec, loss, out, ctc::g_hvp_diag, st);
     if (ef != hipSuccess) return hip_fail(ef, "fused hvp launch");
-    only_if = reinterpret_cast<const int *>(wsf + ctc::make_hvp_fused_layout(B, T, U).off_flags);
+    return CTC_AMD_OK;
   }
-  hipError_t e = ctc::run_emit_scan(p, L, ws, loss, 2, st, only_if);
+  hipError_t e = ctc::run_emit_scan(p, L, ws, loss, 2, st);
   if (e != hipSuccess) return hip_fail(e, "emit/scan launch");
   if (grad) {
     e = ctc::run_grad(p, L, ws, nullptr, grad, st);
     if (e != hipSuccess) return hip_fail(e, "grad launch");
   }
-  e = ctc::run_hvp(p, L, ws, vec, out, st, only_if);
+  e = ctc::run_hvp(p, L, ws, vec, out, st);
   if (e != hipSuccess) return hip_fail(e, "hvp launch");
   return CTC_AMD_OK;
 }

@@ -18,79 +18,16 @@
 // (tangent sweeps, one wavefront per utterance x direction, next step prefetched) -> hvp_out_kernel (wave per frame).
 #include "ctc_fused_common.h"
 #include "ctc_hvp_fused.h"
+#include "ctc_hvp_device.h"
 
 namespace ctc {
 
 using namespace ctc::fused;
 
-dim3 sel_grid(int B, int T);  // ctc_kernels.hip: grid of the selected-utterance kernels
-
-// Extra workspace of the HVP (after Layout::off_extra): tangent emissions [B][T][ERS], tangent lattice rows
-// dalpha/dbeta [B][T+1][SRS] (same layouts as the value rows), dlogP [B].
-struct HvpLayout {
-  size_t off_demis, off_dalpha, off_dbeta, off_dlogp, total;
-};
-static inline HvpLayout make_hvp_layout(const Layout &L, int B, int T) {
-  auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
-  HvpLayout H;
-  size_t o = 0;
-  H.off_demis = o;  o = al(o + (size_t)B * T * L.ERS * 4);
-  H.off_dalpha = o; o = al(o + (size_t)B * (T + 1) * L.SRS * 4);
-  H.off_dbeta = o;  o = al(o + (size_t)B * (T + 1) * L.SRS * 4);
-  H.off_dlogp = o;  o = al(o + (size_t)B * 4);
-  H.total = o;
-  return H;
-}
 size_t hvp_extra_bytes(int kind, int B, int T, int V, int U) {
   Layout L = make_layout(kind, B, T, U, 0);
   // (the fused kernel's region sits behind the log-domain pipeline's: the latter still serves the utterances the former flags)
   return make_hvp_layout(L, B, T).total + (hvp_fused_shape(0, B, T, V, U) ? make_hvp_fused_layout(B, T, U).total : 0);
-}
-// offset of the fused kernel's region inside the extra part of the workspace
-size_t hvp_fused_offset(int kind, int B, int T, int U) {
-  Layout L = make_layout(kind, B, T, U, 0);
-  return make_hvp_layout(L, B, T).total;
-}
-
-// tangent emissions: dE[i] = u[label[i]] (0 beyond the label), [UP] = u[blank], [UP+1] = s . v (logits mode)
-__device__ __forceinline__ void temit_row(const Problem &p, const Layout &L, const float *__restrict__ emis, const float *__restrict__ vec,
-                                          float *__restrict__ demis, int b, int t, int lane) {
-  const long row = (long)b * p.T + t;
-  const int len = clampi(p.logit_length[b], 0, p.T);
-  if (t >= len) return;
-  const int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
-  const int V = p.V;
-  const float *v = vec + row * (long)V;
-  float sv = 0.f;
-  if (p.wrt == 0) {  // u = J v = v - (softmax . v): direction in log-probability space (tools.py:37-39 differentiated)
-    const float *x = p.logits + row * (long)V;
-    const float mx = emis[row * (long)L.ERS + L.UP + 1], l2s = emis[row * (long)L.ERS + L.UP + 2];
-    if (((V & 3) | (int)((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(v)) & 15)) == 0) {  // 16 bytes per lane
-      for (int k = lane * 4; k < V; k += 256) {
-        const float4 xv = *reinterpret_cast<const float4 *>(x + k), vv = *reinterpret_cast<const float4 *>(v + k);
-        sv += (fexp2((xv.x - mx) * LOG2E - l2s) * vv.x + fexp2((xv.y - mx) * LOG2E - l2s) * vv.y) +
-              (fexp2((xv.z - mx) * LOG2E - l2s) * vv.z + fexp2((xv.w - mx) * LOG2E - l2s) * vv.w);
-      }
-    } else {
-      for (int k = lane; k < V; k += 64) sv += fexp2((x[k] - mx) * LOG2E - l2s) * v[k];
-    }
-    sv = wave_sum(sv);
-  }
-  float *drow = demis + row * (long)L.ERS;
-  for (int i = lane; i < L.UP; i += 64) {
-    float d = 0.f;
-    if (i < ll) {
-      int tok = (i < p.label_stride) ? p.labels[(long)b * p.label_stride + i] : p.blank;
-      if (tok >= 0 && tok < V) d = v[tok] - sv;
-    }
-    drow[i] = d;
-  }
-  if (lane == 0) {
-    drow[L.UP] = v[p.blank] - sv;
-    drow[L.UP + 1] = sv;
-    drow[L.UP + 2] = 0.f;
-    drow[L.UP + 3] = 0.f;
-  }
 }
 
 __global__ __launch_bounds__(256) void temit_kernel(Problem p, Layout L, const float *__restrict__ emis,
@@ -100,335 +37,14 @@ __global__ __launch_bounds__(256) void temit_kernel(Problem p, Layout L, const f
   if (row >= (long)p.B * p.T) return;
   temit_row(p, L, emis, vec, demis, (int)(row / p.T), (int)(row % p.T), lane);
 }
-// selected utterances only (ctc_kernels.hip emit_sel_kernel)
-__global__ __launch_bounds__(256) void temit_sel_kernel(Problem p, Layout L, const float *__restrict__ emis, const float *__restrict__ vec,
-                                                         float *__restrict__ demis, const int *__restrict__ only_if) {
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int b = blockIdx.y; b < p.B; b += gridDim.y) {
-    if (only_if[b] == 0) continue;
-    for (int t = blockIdx.x * 4 + w; t < p.T; t += gridDim.x * 4) temit_row(p, L, emis, vec, demis, b, t, lane);
-  }
-}
-
-// One wavefront per (utterance, direction): tangent sweep.  Slot/state conventions = Scan in ctc_kernels.hip.
+// One wavefront per (utterance, direction): tangent sweep (tscan_body, ctc_hvp_device.h).
 template <int KIND, int NL>
 __global__ __launch_bounds__(64) void tscan_kernel(Problem p, Layout L, const float *__restrict__ emis,
                                                     const float *__restrict__ demis, const float *__restrict__ alpha,
                                                     const float *__restrict__ beta, const double *__restrict__ logp,
                                                     float *__restrict__ dalpha, float *__restrict__ dbeta,
-                                                    float *__restrict__ dlogp, const int *__restrict__ only_if) {
-  const int lane = threadIdx.x;
-  const int b = blockIdx.x, dir = blockIdx.y;
-  if (only_if && only_if[b] == 0) return;  // (selected utterances only)
-  const int T = p.T, UP = L.UP;
-  const int len = clampi(p.logit_length[b], 0, T);
-  int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
-  if (ll > p.U || logp[b] == -INFINITY) {
-    if (dir == 0 && lane == 0) dlogp[b] = 0.f;
-    return;  // infeasible: hvp_out_kernel writes zeros
-  }
-  constexpr int PAIR = (KIND == 0) ? 2 : 1;
-  const int tailpos = PAIR * UP;
-  bool norep[NL], norep_next[NL];
-  {
-    const int32_t *lab = p.labels + (long)b * p.label_stride;
-    auto tok = [&](int i) -> int { return (i >= 0 && i < ll) ? ((i < p.label_stride) ? lab[i] : p.blank) : -1 - (i < 0); };
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      int i = lane * NL + j;
-      norep[j] = (i == 0) || tok(i) != tok(i - 1);
-      norep_next[j] = tok(i + 1) != tok(i);
-    }
-  }
-  const float *vrows = (dir == 0 ? alpha : beta) + (long)b * (T + 1) * L.SRS;
-  float *drows = (dir == 0 ? dalpha : dbeta) + (long)b * (T + 1) * L.SRS;
-  const float *erows = emis + (long)b * T * L.ERS;
-  const float *derows = demis + (long)b * T * L.ERS;
-
-  struct Row { float c[NL], o[NL], cx; double off; };  // a value row in the chain's NATIVE layout
-  struct Em { float y[NL], bl, dy[NL], dbl; };
-  // One step's inputs as loaded (conversions need DPP and therefore the data: they are done at use, so that PF steps of
-  // loads can be in flight).  Wave-uniform values come through vector loads as well (vz: an opaque zero), which keeps
-  // them on vmcnt with the rest instead of serialising on the scalar cache.
-  struct Raw { float a[NL], bb[NL], tl, oh, ol, y[NL], bl, dy[NL], dbl; };
-  int vz;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
-  auto load_row_raw = [&](Raw &w, int trow) {
-    const float *q = vrows + (long)trow * L.SRS;
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      const int i = lane * NL + j;
-      if constexpr (KIND == 0) { float2 v = *reinterpret_cast<const float2 *>(q + 2 * i); w.a[j] = v.x; w.bb[j] = v.y; }
-      else { w.a[j] = q[i]; w.bb[j] = NEG; }
-    }
-    w.tl = q[tailpos + vz]; w.oh = q[tailpos + 2 + vz]; w.ol = q[tailpos + 3 + vz];
-  };
-  auto load_raw = [&](Raw &w, int k) {  // inputs of step k: emissions of the frame it consumes, the value row it produces
-    const int kk = k < len ? k : len - 1;
-    const int t = dir == 0 ? kk : len - 1 - kk;
-    load_row_raw(w, dir == 0 ? t + 1 : t);
-    const float *q = erows + (long)t * L.ERS, *dq = derows + (long)t * L.ERS;
-#pragma unroll
-    for (int j = 0; j < NL; ++j) { w.y[j] = q[lane * NL + j]; w.dy[j] = dq[lane * NL + j]; }
-    w.bl = q[UP + vz];
-    w.dbl = dq[UP + vz];
-  };
-  auto to_row = [&](const Raw &w, Row &r) {
-    if (dir == 0) {  // alpha rows are stored in native layout
-#pragma unroll
-      for (int j = 0; j < NL; ++j) { r.c[j] = w.a[j]; r.o[j] = w.bb[j]; }
-      r.cx = w.tl;
-    } else {  // beta rows: slot i = state l = i+1, tail = l = 0  ->  native: slot i = state_c(l = i), cx = l = UP
-#pragma unroll
-      for (int j = NL - 1; j > 0; --j) r.c[j] = w.a[j - 1];
-      r.c[0] = from_prev_lane(w.a[NL - 1], w.tl);
-      r.cx = readlane_f(w.a[NL - 1], 63);
-#pragma unroll
-      for (int j = 0; j < NL; ++j) r.o[j] = w.bb[j];
-    }
-    r.off = (double)w.oh + (double)w.ol;
-  };
-  // tangent state (natural-log units), native layout
-  float dc[NL], dob[NL], dcx = 0.f;
-#pragma unroll
-  for (int j = 0; j < NL; ++j) { dc[j] = 0.f; dob[j] = 0.f; }
-  auto store_tangent = [&](int t) {
-    float *q = drows + (long)t * L.SRS;
-    if (dir == 0) {
-#pragma unroll
-      for (int j = 0; j < NL; ++j) {
-        const int i = lane * NL + j;
-        if constexpr (KIND == 0) *reinterpret_cast<float2 *>(q + 2 * i) = make_float2(dc[j], dob[j]);
-        else q[i] = dc[j];
-      }
-      if (lane == 0) q[tailpos] = dcx;
-    } else {  // back to the stored beta layout: slot i = l = i+1 (next slot's c), tail = l = 0
-      float cs[NL];
-#pragma unroll
-      for (int j = 0; j < NL - 1; ++j) cs[j] = dc[j + 1];
-      cs[NL - 1] = from_next_lane(dc[0], dcx);
-#pragma unroll
-      for (int j = 0; j < NL; ++j) {
-        const int i = lane * NL + j;
-        if constexpr (KIND == 0) *reinterpret_cast<float2 *>(q + 2 * i) = make_float2(cs[j], dob[j]);
-        else q[i] = cs[j];
-      }
-      if (lane == 0) q[tailpos] = dc[0];
-    }
-  };
-  // Weight of the first argument of a two-way log-sum-exp whose result `res` is known; the second weight is taken as
-  // 1 - w so the pair sums to one exactly: tangents carry a large common component (the running sum of the blank
-  // direction) that must pass through unchanged, d = d2 + w (d1 - d2).  Unreachable results carry no weight.
-  auto w = [](float arg, float res) -> float { return res > NEG_THR ? fminf(fexp2(arg - res), 1.0f) : 0.f; };
-  Row prev;
-  {
-    Raw w0;
-    load_row_raw(w0, dir == 0 ? 0 : len);
-    to_row(w0, prev);
-  }
-  store_tangent(dir == 0 ? 0 : len);  // boundary rows have zero tangent
-  // steps of look-ahead (register ring, statically indexed: the loop is unrolled by TPF); shallower for long labels, whose
-  // rows fill the register file
-  constexpr int TPF = NL <= 2 ? 8 : (NL == 4 ? 4 : (NL == 8 ? 2 : 1));
-  Raw ring[TPF];
-  if (len > 0) {
-    static_for<0, TPF>([&](auto D) { load_raw(ring[decltype(D)::value], decltype(D)::value); });
-    int k0 = 0;
-    auto step = [&](auto D) __attribute__((always_inline)) {
-      constexpr int d = decltype(D)::value;
-      const int k = k0 + d;
-      {
-        const int t = dir == 0 ? k : len - 1 - k;           // frame consumed
-        const int tres = dir == 0 ? t + 1 : t;              // row produced
-        Row next;
-        Em e;
-        to_row(ring[d], next);
-#pragma unroll
-        for (int j = 0; j < NL; ++j) { e.y[j] = ring[d].y[j]; e.dy[j] = ring[d].dy[j]; }
-        e.bl = ring[d].bl;
-        e.dbl = ring[d].dbl;
-        load_raw(ring[d], k + TPF);                         // refill the slot (clamped at the end)
-      const float doff = (float)(prev.off - next.off);    // rows carry different renormalisation offsets
-      if constexpr (KIND == 0) {
-        if (dir == 0) {
-          // alpha step (classic_ctc_loss.py:415-451): m = c (+) o, c' = bl + m, o' = y + (o (+) xin)
-          float dm[NL], x[NL], dx[NL];
-#pragma unroll
-          for (int j = 0; j < NL; ++j) {
-            const float m = next.c[j] - e.bl - doff;      // m in the units of the previous row
-            dm[j] = dob[j] + w(prev.c[j], m) * (dc[j] - dob[j]);
-            x[j] = norep_next[j] ? m : prev.c[j];
-            dx[j] = norep_next[j] ? dm[j] : dc[j];
-          }
-          const float xin0 = from_prev_lane(x[NL - 1], prev.cx), dxin0 = from_prev_lane(dx[NL - 1], dcx);
-#pragma unroll
-          for (int j = NL - 1; j >= 0; --j) {
-            const float xin = (j == 0) ? xin0 : x[j - 1], dxin = (j == 0) ? dxin0 : dx[j - 1];
-            const float Lr = next.o[j] - e.y[j] - doff;
-            dob[j] = e.dy[j] + dxin + w(prev.o[j], Lr) * (dob[j] - dxin);
-            dc[j] = e.dbl + dm[j];
-          }
-          dcx += e.dbl;
-        } else {
-          // beta step (classic_ctc_loss.py:349-364): c' = h (+) ee, o' = xin (+) ee, h = bl + c, ee = y + o
-          float h[NL], ee[NL], dh[NL], dee[NL], x[NL], dx[NL], dpn[NL];
-#pragma unroll
-          for (int j = 0; j < NL; ++j) {
-            h[j] = e.bl + prev.c[j] + doff;               // arguments in the units of the produced row
-            ee[j] = e.y[j] + prev.o[j] + doff;
-            dh[j] = e.dbl + dc[j];
-            dee[j] = e.dy[j] + dob[j];
-            dpn[j] = dee[j] + w(h[j], next.c[j]) * (dh[j] - dee[j]);
-            x[j] = norep[j] ? next.c[j] : h[j];
-            dx[j] = norep[j] ? dpn[j] : dh[j];
-          }
-          const float cxn = prev.cx + e.bl + doff, dcxn = dcx + e.dbl;
-          const float xinl = from_next_lane(x[0], cxn), dxinl = from_next_lane(dx[0], dcxn);
-#pragma unroll
-          for (int j = 0; j < NL; ++j) {
-            const float xin = (j == NL - 1) ? xinl : x[j + 1], dxin = (j == NL - 1) ? dxinl : dx[j + 1];
-            dob[j] = dee[j] + w(xin, next.o[j]) * (dxin - dee[j]);
-            dc[j] = dpn[j];
-          }
-          dcx = dcxn;
-        }
-      } else {
-        if (dir == 0) {
-          // simplified alpha step: a'(l=i+1) = (bl + a(i+1)) (+) (y_i + a(i))   (simplified_ctc_loss.py:393-424)
-          const float pin0 = from_prev_lane(prev.c[NL - 1], prev.cx), dpin0 = from_prev_lane(dc[NL - 1], dcx);
-#pragma unroll
-          for (int j = NL - 1; j >= 0; --j) {
-            const float pin = (j == 0) ? pin0 : prev.c[j - 1], dpin = (j == 0) ? dpin0 : dc[j - 1];
-            const float r = next.c[j] - doff;
-            const float d2 = e.dy[j] + dpin;
-            dc[j] = d2 + w(e.bl + prev.c[j], r) * (e.dbl + dc[j] - d2);
-          }
-          dcx += e.dbl;
-        } else {
-          // simplified beta step: b'(l=i) = (bl + b(i)) (+) (y_i + b(i+1))       (simplified_ctc_loss.py:327-343)
-          const float nin = from_next_lane(prev.c[0], prev.cx), dnin = from_next_lane(dc[0], dcx);
-#pragma unroll
-          for (int j = 0; j < NL; ++j) {
-            const float nx = (j == NL - 1) ? nin : prev.c[j + 1], dnx = (j == NL - 1) ? dnin : dc[j + 1];
-            const float r = next.c[j] - doff;
-            const float d2 = e.dy[j] + dnx;
-            dc[j] = d2 + w(e.bl + prev.c[j], r) * (e.dbl + dc[j] - d2);
-          }
-          dcx += e.dbl;
-        }
-      }
-        store_tangent(tres);
-        prev = next;
-      }
-    };
-    for (; k0 + TPF <= len; k0 += TPF) static_for<0, TPF>(step);
-    static_for<0, TPF>([&](auto D) {
-      if (k0 + decltype(D)::value < len) step(D);
-    });
-  }
-  if (dir == 0) {
-    // dlogP = tangent of alpha[len, label_length] (classic: of closed (+) open there)
-    float mine = 0.f;
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      const int i = lane * NL + j;
-      if (i == ll - 1) {
-        if constexpr (KIND == 0) {
-          const float r = lse2(prev.c[j], prev.o[j]);
-          mine = dob[j] + w(prev.c[j], r) * (dc[j] - dob[j]);
-        } else {
-          mine = dc[j];
-        }
-      }
-    }
-    mine = wave_sum(mine);
-    if (lane == 0) dlogp[b] = (ll == 0) ? dcx : mine;
-  }
-}
-
-// One wavefront per frame: d(posterior) scattered by token, chain rule through log-softmax for logits.
-template <int KIND>
-__device__ __forceinline__ void hvp_out_row(const Problem &p, const Layout &L, const float *__restrict__ emis,
-                                            const float *__restrict__ demis, const float *__restrict__ alpha,
-                                            const float *__restrict__ beta, const float *__restrict__ dalpha,
-                                            const float *__restrict__ dbeta, const double *__restrict__ logp,
-                                            const float *__restrict__ dlogp, const float *__restrict__ vec,
-                                            float *__restrict__ out, float *bin, int b, int t, int lane) {
-  const long row = (long)b * p.T + t;
-  const int V = p.V, UP = L.UP;
-  float *o = out + row * (long)V;
-  const int len = clampi(p.logit_length[b], 0, p.T);
-  const double lp = logp[b];
-  int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
-  if (t >= len || lp == -INFINITY || ll > p.U) {
-    for (int k = lane; k < V; k += 64) __builtin_nontemporal_store(0.f, o + k);  // the Hessian vanishes there (base_loss.py:240-258)
-    return;
-  }
-  for (int k = lane; k < V; k += 64) bin[k] = 0.f;
-  wave_lds_fence();
-  constexpr int PAIR = (KIND == 0) ? 2 : 1;
-  const int tailpos = PAIR * UP;
-  const int32_t *lab = p.labels + (long)b * p.label_stride;
-  const long ra_i = ((long)b * (p.T + 1) + (KIND == 0 ? t + 1 : t)) * L.SRS, rb_i = ((long)b * (p.T + 1) + t + 1) * L.SRS;
-  const float *ra = alpha + ra_i, *rb = beta + rb_i, *da = dalpha + ra_i, *db = dbeta + rb_i;
-  const double scale = (double)ra[tailpos + 2] + (double)ra[tailpos + 3] + (double)rb[tailpos + 2] + (double)rb[tailpos + 3] - lp;
-  const float dlp = dlogp[b];
-  auto post = [&](float a_, float b_) -> float { return fminf(fexp2((float)((double)a_ + (double)b_ + scale)), 1.0f); };
-  auto post3 = [&](float a_, float b_, float c_) -> float { return fminf(fexp2((float)((double)a_ + (double)b_ + (double)c_ + scale)), 1.0f); };
-  float dblank = 0.f;
-  if constexpr (KIND == 0) {
-    for (int i = lane; i < UP; i += 64) {
-      const float2 a = *reinterpret_cast<const float2 *>(ra + 2 * i), bb = *reinterpret_cast<const float2 *>(rb + 2 * i);
-      const float2 ta = *reinterpret_cast<const float2 *>(da + 2 * i), tb = *reinterpret_cast<const float2 *>(db + 2 * i);
-      dblank += post(a.x, bb.x) * (ta.x + tb.x - dlp);
-      if (i < ll) {
-        const float dq = post(a.y, bb.y) * (ta.y + tb.y - dlp);
-        const int tok = (i < p.label_stride) ? lab[i] : p.blank;
-        if (tok >= 0 && tok < V && tok != p.blank) atomicAdd(&bin[tok], dq);
-      }
-    }
-    if (lane == 0) dblank += post(ra[2 * UP], rb[2 * UP]) * (da[2 * UP] + db[2 * UP] - dlp);
-  } else {
-    const float *er = emis + row * (long)L.ERS, *der = demis + row * (long)L.ERS;
-    const float bl = er[UP], dbl = der[UP];
-    for (int i = lane; i < UP; i += 64) {
-      const float ai = ra[i], bi = rb[i];  // state l = i+1 in both rows
-      dblank += post3(ai, bi, bl) * (da[i] + db[i] + dbl - dlp);
-      if (i < ll) {
-        const float aprev = (i == 0) ? ra[UP] : ra[i - 1], daprev = (i == 0) ? da[UP] : da[i - 1];
-        const float dq = post3(aprev, er[i], bi) * (daprev + der[i] + db[i] - dlp);
-        const int tok = (i < p.label_stride) ? lab[i] : p.blank;
-        if (tok >= 0 && tok < V && tok != p.blank) atomicAdd(&bin[tok], dq);
-      }
-    }
-    if (lane == 0) dblank += post3(ra[UP], rb[UP], bl) * (da[UP] + db[UP] + dbl - dlp);
-  }
-  dblank = wave_sum(dblank);
-  if (lane == 0) bin[p.blank] = dblank;
-  wave_lds_fence();
-  if (p.wrt == 0) {
-    const float *x = p.logits + row * (long)V, *v = vec + row * (long)V;
-    const float mx = emis[row * (long)L.ERS + UP + 1], l2s = emis[row * (long)L.ERS + UP + 2];
-    const float sv = demis[row * (long)L.ERS + UP + 1];
-    if (((V & 3) | (int)((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(o)) & 15)) == 0) {
-      typedef float v4f __attribute__((ext_vector_type(4)));
-      for (int k = lane * 4; k < V; k += 256) {  // 16 bytes per lane in and out
-        const float4 xv = *reinterpret_cast<const float4 *>(x + k), vv = *reinterpret_cast<const float4 *>(v + k);
-        const float4 bq = *reinterpret_cast<const float4 *>(bin + k);
-        const v4f r = {-bq.x + fexp2((xv.x - mx) * LOG2E - l2s) * (vv.x - sv), -bq.y + fexp2((xv.y - mx) * LOG2E - l2s) * (vv.y - sv),
-                       -bq.z + fexp2((xv.z - mx) * LOG2E - l2s) * (vv.z - sv), -bq.w + fexp2((xv.w - mx) * LOG2E - l2s) * (vv.w - sv)};
-        __builtin_nontemporal_store(r, reinterpret_cast<v4f *>(o + k));
-      }
-    } else {
-      for (int k = lane; k < V; k += 64) {
-        const float s = fexp2((x[k] - mx) * LOG2E - l2s);
-        __builtin_nontemporal_store(-bin[k] + s * (v[k] - sv), o + k);  // H_lp u + (diag(s) - s s^T) v
-      }
-    }
-  } else {
-    for (int k = lane; k < V; k += 64) __builtin_nontemporal_store(-bin[k], o + k);
-  }
+                                                    float *__restrict__ dlogp) {
+  tscan_body<KIND, NL>(p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp, blockIdx.x, blockIdx.y, threadIdx.x);
 }
 
 template <int KIND>
@@ -437,21 +53,11 @@ __global__ __launch_bounds__(256) void hvp_out_kernel(Problem p, Layout L, const
                                                        const float *__restrict__ beta, const float *__restrict__ dalpha,
                                                        const float *__restrict__ dbeta, const double *__restrict__ logp,
                                                        const float *__restrict__ dlogp, const float *__restrict__ vec,
-                                                       float *__restrict__ out, int wpb, const int *__restrict__ only_if) {
+                                                       float *__restrict__ out, int wpb) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps everything derived from it in SGPRs
   float *bin = lds + (long)w * p.V;
-  if (only_if) {  // selected utterances only: blockIdx.y strides over utterances, blockIdx.x over the frames of a selected one
-    for (int b = blockIdx.y; b < p.B; b += gridDim.y) {
-      if (only_if[b] == 0) continue;
-      for (int t = blockIdx.x * wpb + w; t < p.T; t += gridDim.x * wpb) {
-        hvp_out_row<KIND>(p, L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, bin, b, t, lane);
-        wave_lds_fence();  // the bins are reused by the next frame of this wavefront
-      }
-    }
-    return;
-  }
   const long row = (long)blockIdx.x * wpb + w;
   if (row >= (long)p.B * p.T) return;
   hvp_out_row<KIND>(p, L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, bin, (int)(row / p.T), (int)(row % p.T), lane);
@@ -460,14 +66,14 @@ __global__ __launch_bounds__(256) void hvp_out_kernel(Problem p, Layout L, const
 template <int KIND>
 static hipError_t launch_hvp(const Problem &p, const Layout &L, const float *emis, float *demis, const float *alpha,
                              const float *beta, float *dalpha, float *dbeta, const double *logp, float *dlogp,
-                             const float *vec, float *out, const int *only_if, hipStream_t st) {
+                             const float *vec, float *out, hipStream_t st) {
   dim3 grid(p.B, 2), block(64);
   switch (L.NL) {
-    case 1: hipLaunchKernelGGL((tscan_kernel<KIND, 1>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp, only_if); break;
-    case 2: hipLaunchKernelGGL((tscan_kernel<KIND, 2>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp, only_if); break;
-    case 4: hipLaunchKernelGGL((tscan_kernel<KIND, 4>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp, only_if); break;
-    case 8: hipLaunchKernelGGL((tscan_kernel<KIND, 8>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp, only_if); break;
-    case 16: hipLaunchKernelGGL((tscan_kernel<KIND, 16>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp, only_if); break;
+    case 1: hipLaunchKernelGGL((tscan_kernel<KIND, 1>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp); break;
+    case 2: hipLaunchKernelGGL((tscan_kernel<KIND, 2>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp); break;
+    case 4: hipLaunchKernelGGL((tscan_kernel<KIND, 4>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp); break;
+    case 8: hipLaunchKernelGGL((tscan_kernel<KIND, 8>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp); break;
+    case 16: hipLaunchKernelGGL((tscan_kernel<KIND, 16>), grid, block, 0, st, p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp); break;
     default: return hipErrorInvalidValue;
   }
   hipError_t e = hipGetLastError();
@@ -475,15 +81,13 @@ static hipError_t launch_hvp(const Problem &p, const Layout &L, const float *emi
   const long rows = (long)p.B * p.T;
   int wpb = 4;
   while (wpb > 1 && (size_t)wpb * p.V * 4 > 64 * 1024) wpb >>= 1;
-  const dim3 ogrid = only_if ? sel_grid(p.B, p.T) : dim3((unsigned)((rows + wpb - 1) / wpb));
-  hipLaunchKernelGGL(hvp_out_kernel<KIND>, ogrid, dim3(64 * wpb), (size_t)wpb * p.V * 4, st, p,
-                     L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, wpb, only_if);
+  hipLaunchKernelGGL(hvp_out_kernel<KIND>, dim3((unsigned)((rows + wpb - 1) / wpb)), dim3(64 * wpb), (size_t)wpb * p.V * 4, st, p,
+                     L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, wpb);
   return hipGetLastError();
 }
 
-// values must already be in the workspace (run_emit_scan with both directions); only_if != NULL: the utterances with a non-zero
-// entry only (those the fused kernel flagged), everything else of `out` is left alone
-hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec, float *out, hipStream_t st, const int *only_if) {
+// values must already be in the workspace (run_emit_scan with both directions)
+hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec, float *out, hipStream_t st) {
   const long rows = (long)p.B * p.T;
   if (rows == 0) return hipSuccess;
   const HvpLayout H = make_hvp_layout(L, p.B, p.T);
@@ -497,12 +101,11 @@ hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec
   float *dbeta = reinterpret_cast<float *>(ex + H.off_dbeta);
   float *dlogp = reinterpret_cast<float *>(ex + H.off_dlogp);
   // (four rows per wavefront, as emit4_kernel does, was tried here and lost: 195 against 172 us at the north-star shape)
-  if (only_if) hipLaunchKernelGGL(temit_sel_kernel, sel_grid(p.B, p.T), dim3(256), 0, st, p, L, emis, vec, demis, only_if);
-  else hipLaunchKernelGGL(temit_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, L, emis, vec, demis);
+  hipLaunchKernelGGL(temit_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, L, emis, vec, demis);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return p.kind == 0 ? launch_hvp<0>(p, L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, only_if, st)
-                     : launch_hvp<1>(p, L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, only_if, st);
+  return p.kind == 0 ? launch_hvp<0>(p, L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, st)
+                     : launch_hvp<1>(p, L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, st);
 }
 
 }  // namespace ctc

@@ -18,14 +18,18 @@
 //     meeting point of the chains;
 //   * dq is scattered by token with integer LDS atomics; the fixed-point scale is chosen per frame from the wave-wide sum of
 //     |dq| (a bin can never exceed it), so no bound on the tangents is assumed.
-// What the number format cannot hold is flagged per utterance exactly as in ctc_fused6.hip (D1..D6); the caller then runs
-// the log-domain pipeline of ctc_hvp.hip restricted to the flagged utterances (Problem::only_if).
+// What the number format cannot hold is flagged per utterance exactly as in ctc_fused6.hip (D1..D6); a flagged utterance is
+// redone inside the same launch by its own workgroup with the log-domain building blocks of ctc_hvp.hip (emit -> scan ->
+// tangent emissions -> tangent scan -> output rows, over the full-row regions of the workspace): a call is one launch whatever
+// it meets, and a batch in which every utterance is flagged costs what the five-launch pipeline costs.
 //
 // Instantiated for logits input, contiguous float32 [B,T,V] with V <= 256 (V % 4 == 0) and U <= 128 (one or two label positions
 // per lane): 8 wavefronts, 6-frame blocks, 143 KB of LDS.  Other shapes keep the log-domain pipeline.
 #include "ctc_fused_common.h"
 #include "ctc_swap_reduce.h"
 #include "ctc_hvp_fused.h"
+#include "ctc_v1_device.h"   // emit_row, scan_body: the log-domain building blocks, run in this launch for flagged utterances
+#include "ctc_hvp_device.h"  // temit_row, tscan_body, hvp_out_row
 
 #ifndef CTC_FUSED_KIND
 #error "compile with -DCTC_FUSED_KIND=0 (classic) or 1 (simplified)"
@@ -74,7 +78,7 @@ struct Lds {
   int bins[2 * NH][V + 4];
   float dump[NW][64];
   double l2s[NW];
-  int flag, feasible, lp_int;
+  int flag, feasible, lp_int, mode;
   float cf, dlp;
 };
 
@@ -473,17 +477,25 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL> &S, Lds<KIND, NL> &
     t = t < len ? t : len - 1;
     return t < 0 ? 0 : t;
   };
-  float4 xb[NQ], vb[NQ];
+  // rows are loaded PFD blocks ahead of their use, in a ring of register sets addressed by (block mod PFD) at COMPILE time (the
+  // loop is unrolled by PFD): a 6-frame block lasts ~0.7 us, an HBM load under load ~2 us -- with one block of look-ahead every
+  // iteration waited for memory (phase 1: 165 us instead of ~70)
+  constexpr int PFD = 4;
+  float4 xb[PFD][NQ], vb[PFD][NQ];
+  static_for<0, PFD>([&](auto R) {
+    constexpr int r = decltype(R)::value;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    xb[q] = make_float4(0.f, 0.f, 0.f, 0.f); vb[q] = xb[q];
-    if (nb > 0) S.load_xv(xb[q], vb[q], fr(0, P0 + q));
-  }
+    for (int q = 0; q < NQ; ++q) {
+      xb[r][q] = make_float4(0.f, 0.f, 0.f, 0.f); vb[r][q] = xb[r][q];
+      if (nb > 0) S.load_xv(xb[r][q], vb[r][q], fr(r, P0 + q));
+    }
+  });
   double acc = 0.0;
   float zmin[NL], zb = 1.0f;
 #pragma unroll
   for (int j = 0; j < NL; ++j) zmin[j] = 1.0f;
-  for (int it = 0; it <= geo.NB; ++it) {
+  auto body = [&](auto R, int it) __attribute__((always_inline)) {
+    constexpr int r = decltype(R)::value;  // = it mod PFD
     const int j = it;
     if (j < nb) {
       const int g = geo.absblock(1, SIDE, j);
@@ -491,9 +503,9 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL> &S, Lds<KIND, NL> &
       float(*E)[Cfg<NL>::ES] = lds.E[SIDE][j % 3];
       float4 xq[NQ], vq[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) { xq[q] = xb[q]; vq[q] = vb[q]; }
+      for (int q = 0; q < NQ; ++q) { xq[q] = xb[r][q]; vq[q] = vb[r][q]; }
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) S.load_xv(xb[q], vb[q], fr(j + 1, P0 + q));  // next block's rows: the whole iteration to arrive
+      for (int q = 0; q < NQ; ++q) S.load_xv(xb[r][q], vb[r][q], fr(j + PFD, P0 + q));  // refill the slot: PFD blocks ahead
       float prod = 1.f;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
@@ -516,6 +528,11 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL> &S, Lds<KIND, NL> &
       acc += (double)flog2(prod);
     }
     block_barrier_raw();
+  };
+  for (int it0 = 0; it0 <= geo.NB; it0 += PFD) {
+    static_for<0, PFD>([&](auto R) {
+      if (it0 + decltype(R)::value <= geo.NB) body(R, it0 + decltype(R)::value);
+    });
   }
   bool bad = !(zb >= EMIS_MIN) || !(acc - acc == 0.0);
 #pragma unroll
@@ -557,11 +574,22 @@ __device__ __forceinline__ void run_main(const Problem &p, float *__restrict__ r
         const int nv = geo.nvof(g);
         const float(*E)[C::ES] = lds.E[DIR][j % 3];
         spill(geo.slot(DIR == 0 ? BLK * g : BLK * g + nv));
-        for (int d = 0; d < nv; ++d) {
-          Emis<NL> e;
-          read_E<NL>(E[d], lane, e);
-          S.step(e);
-          if ((d + 1) % RN == 0 || d == nv - 1) S.renorm();
+        if (nv == BLK) {
+          // the emission rows of the whole block go to registers first: the sequential chain never waits for an LDS round trip
+          Emis<NL> eb[BLK];
+          static_for<0, BLK>([&](auto D) { read_E<NL>(E[decltype(D)::value], lane, eb[decltype(D)::value]); });
+          static_for<0, BLK>([&](auto D) {
+            constexpr int d = decltype(D)::value;
+            S.step(eb[d]);
+            if ((d + 1) % RN == 0) S.renorm();
+          });
+        } else {
+          for (int d = 0; d < nv; ++d) {
+            Emis<NL> e;
+            read_E<NL>(E[d], lane, e);
+            S.step(e);
+            if ((d + 1) % RN == 0 || d == nv - 1) S.renorm();
+          }
         }
       }
       block_barrier_raw();
@@ -613,15 +641,16 @@ __device__ __forceinline__ void run_main(const Problem &p, float *__restrict__ r
       lds.lp_int = EX + fe;
       lds.cf = __builtin_amdgcn_rcpf(ldexp_f(s, -fe));
       lds.dlp = ds * __builtin_amdgcn_rcpf(s);  // d log P (natural-log units, blank gauge)
-      lds.feasible = (fl == 0);
+      lds.feasible = (fl == 0) && !(lds.mode & 1);
       lds.flag = fl;
     }
   }
   __syncthreads();
   if (lds.feasible == 0) {
-    if (DIR == 0 && lane == 0) flag_ws[b] = lds.flag;
+    if (DIR == 0 && lane == 0) flag_ws[b] = lds.mode ? 0 : lds.flag;  // (timing modes: nothing for the fallback to do)
     return;
   }
+  const bool idle = (lds.mode & 2) != 0;
   const int lp_int = lds.lp_int;
   const float cf30 = ldexp_f(lds.cf, 30);
   const float dlp = lds.dlp;
@@ -632,7 +661,7 @@ __device__ __forceinline__ void run_main(const Problem &p, float *__restrict__ r
     int kflag = 0;
     for (int it = 0; it <= geo.NB + 2; ++it) {
       const int j = it - 2;
-      if (j >= 0 && j < nb) {
+      if (j >= 0 && j < nb && !idle) {
         const int g = geo.absblock(2, DIR, j);
         const int nv = geo.nvof(g);
         const float(*E)[C::ES] = lds.E[DIR][j % 3];
@@ -652,14 +681,9 @@ __device__ __forceinline__ void run_main(const Problem &p, float *__restrict__ r
           KS = ldexp_f(cf30, imin(kb, KK_MAX));
           K0 = ldexp_f(cf30, imin(kc, KK_MAX));
         };
-        for (int d = 0; d < nv; ++d) {
-          Emis<NL> e;
-          read_E<NL>(E[d], lane, e);
-          RRow<NL> r;
-          read_R<NL>(RR[d], lane, r);
-          const int qd = grp(d);
+        auto one = [&](int d, int qd, bool ren, const Emis<NL> &e, const RRow<NL> &r, int kRq) __attribute__((always_inline)) {
           if (qd != q) {
-            q = qd; kR = KG[qd][lane];
+            q = qd; kR = kRq;
             ks = (DIR == 0) ? from_next_lane_i(kR, r.kx) : from_prev_lane_i(kR, r.kx);
             k0r = readlane_i(kR, DIR == 0 ? 0 : 63);
             setK();
@@ -732,7 +756,33 @@ __device__ __forceinline__ void run_main(const Problem &p, float *__restrict__ r
           }
           KLr[d][lane] = KL;
           if constexpr (!(KIND == 0 && DIR == 0)) S.step(e);
-          if ((d + 1) % RN == 0 || d == nv - 1) { S.renorm(); setK(); }
+          if (ren) { S.renorm(); setK(); }
+        };
+        if (nv == BLK) {
+          // emission rows of the whole block and the exponent groups up front, R rows PR frames ahead of their use
+          constexpr int PR = 2;
+          Emis<NL> eb[BLK];
+          RRow<NL> rb[BLK];
+          int kq[NG];
+          static_for<0, NG>([&](auto Q) { kq[decltype(Q)::value] = KG[decltype(Q)::value][lane]; });
+          static_for<0, PR>([&](auto D) { read_R<NL>(RR[decltype(D)::value], lane, rb[decltype(D)::value]); });
+          static_for<0, BLK>([&](auto D) { read_E<NL>(E[decltype(D)::value], lane, eb[decltype(D)::value]); });
+          static_for<0, BLK>([&](auto D) {
+            constexpr int d = decltype(D)::value;
+            if constexpr (d + PR < BLK) read_R<NL>(RR[d + PR], lane, rb[d + PR]);
+            constexpr int sst = (KIND == 0 && DIR == 1) ? BLK - d : BLK - 1 - d;
+            constexpr int qd = (sst > 0 ? sst - 1 : 0) / RN;
+            one(d, qd, (d + 1) % RN == 0, eb[d], rb[d], kq[qd]);
+          });
+        } else {
+          for (int d = 0; d < nv; ++d) {
+            Emis<NL> e;
+            read_E<NL>(E[d], lane, e);
+            RRow<NL> r;
+            read_R<NL>(RR[d], lane, r);
+            const int qd = grp(d);
+            one(d, qd, (d + 1) % RN == 0 || d == nv - 1, e, r, KG[qd][lane]);
+          }
         }
       }
       block_barrier_raw();
@@ -740,7 +790,7 @@ __device__ __forceinline__ void run_main(const Problem &p, float *__restrict__ r
     if (__builtin_amdgcn_ballot_w64(kflag != 0) != 0 && lane == 0) atomicOr(&lds.flag, 32);  // D5
   }
   __syncthreads();
-  if (DIR == 0 && lane == 0) flag_ws[b] = lds.flag;
+  if (DIR == 0 && lane == 0) flag_ws[b] = lds.mode ? 0 : lds.flag;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -769,6 +819,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const float *__r
     __syncthreads();
   }
   if (lds.feasible == 0) return;
+  const bool idle = (lds.mode & 2) != 0;
   Chain<KIND, NL, RDIR> S;
   S.init_labels(p, b, lane, ll);
   const int nb = geo.nblocks(2, SIDE);
@@ -783,7 +834,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const float *__r
   load_ck<NL>(ck_next, ck_rows, ck_k, ck_slot(0), lane);
   for (int it = 0; it <= geo.NB + 2; ++it) {
     const int j = it - 1;
-    if (j >= 0 && j < nb) {
+    if (j >= 0 && j < nb && !idle) {
       const int g = geo.absblock(2, SIDE, j);
       const int nv = geo.nvof(g);
       const float(*E)[C::ES] = lds.E[SIDE][j % 3];
@@ -800,14 +851,38 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const float *__r
         ++s;
         if (s % RN == 0 && more) { S.renorm(); KG[s / RN][lane] = S.k; }
       };
+      Emis<NL> eb[BLK];  // full blocks: the emission rows go to registers before the chain starts
+      if (nv == BLK) static_for<0, BLK>([&](auto D) { read_E<NL>(E[decltype(D)::value], lane, eb[decltype(D)::value]); });
+      auto stpb = [&](auto D) __attribute__((always_inline)) { S.step(eb[decltype(D)::value]); };
       if constexpr (SIDE == 0) {
         put(nv - 1);
-        for (int d = nv - 1; d >= 1; --d) { stp(d); put(d - 1); after(d > 1); }
+        if (nv == BLK) {
+          static_for<0, BLK - 1>([&](auto I) {
+            constexpr int d = BLK - 1 - decltype(I)::value;
+            stpb(std::integral_constant<int, d>{}); put(d - 1); after(d > 1);
+          });
+        } else {
+          for (int d = nv - 1; d >= 1; --d) { stp(d); put(d - 1); after(d > 1); }
+        }
       } else if constexpr (KIND == 0) {
-        for (int i = 0; i < nv; ++i) { stp(nv - 1 - i); put(nv - 1 - i); after(i < nv - 1); }
+        if (nv == BLK) {
+          static_for<0, BLK>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            stpb(std::integral_constant<int, BLK - 1 - i>{}); put(BLK - 1 - i); after(i < BLK - 1);
+          });
+        } else {
+          for (int i = 0; i < nv; ++i) { stp(nv - 1 - i); put(nv - 1 - i); after(i < nv - 1); }
+        }
       } else {
         put(nv - 1);
-        for (int i = 1; i < nv; ++i) { stp(nv - i); put(nv - 1 - i); after(i < nv - 1); }
+        if (nv == BLK) {
+          static_for<1, BLK>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            stpb(std::integral_constant<int, BLK - i>{}); put(BLK - 1 - i); after(i < BLK - 1);
+          });
+        } else {
+          for (int i = 1; i < nv; ++i) { stp(nv - i); put(nv - 1 - i); after(i < nv - 1); }
+        }
       }
     }
     block_barrier_raw();
@@ -854,16 +929,25 @@ __device__ __forceinline__ void run_helper(const Problem &p, float4 *__restrict_
     t = t < len ? t : len - 1;
     return t < 0 ? 0 : t;
   };
-  float4 X[FPH], Vv[FPH];
-  float4 ST[FPH];
+  // E-stage rows: a ring of PF2 register sets, loaded PF2 blocks ahead (see estage1); the G stage reads its rows again (they
+  // come from L2: the E stage had them three blocks earlier)
+  constexpr int PF2 = 3;
+  float4 X[PF2][FPH], Vv[PF2][FPH];
+  float SX[PF2][FPH];
+  static_for<0, PF2>([&](auto R) {
+    constexpr int r = decltype(R)::value;
 #pragma unroll
-  for (int q = 0; q < FPH; ++q) {
-    X[q] = make_float4(0.f, 0.f, 0.f, 0.f); Vv[q] = X[q]; ST[q] = X[q];
-    if (nb > 0) { S.load_xv(X[q], Vv[q], fr(0, h + NH * q)); ST[q] = stats[fr(0, h + NH * q)]; }
-  }
+    for (int q = 0; q < FPH; ++q) {
+      X[r][q] = make_float4(0.f, 0.f, 0.f, 0.f); Vv[r][q] = X[r][q]; SX[r][q] = 0.f;
+      if (nb > 0) { S.load_xv(X[r][q], Vv[r][q], fr(r, h + NH * q)); SX[r][q] = stats[fr(r, h + NH * q)].x; }
+    }
+  });
   bool massbad = false;
-  for (int it = 0; it <= geo.NB + 2; ++it) {
-    // rows of the G stage's block (read again: five register sets of two rows each do not fit; they come from L2)
+  const bool idle = (lds.mode & 4) != 0;
+  auto body = [&](auto R, int it) __attribute__((always_inline)) {
+    constexpr int r = decltype(R)::value;  // = it mod PF2
+    if (idle) { block_barrier_raw(); return; }
+    // rows of the G stage's block (read again)
     float4 XG[FPH], VG[FPH], SG[FPH];
     const int gj = it - 3;
     const bool do_g = gj >= 0 && gj < nb;
@@ -875,16 +959,17 @@ __device__ __forceinline__ void run_helper(const Problem &p, float4 *__restrict_
       const int g = geo.absblock(2, DIR, j);
       const int nv = geo.nvof(g);
       float(*E)[C::ES] = lds.E[DIR][j % 3];
-      float4 xq[FPH], vq[FPH], sq[FPH];
+      float4 xq[FPH], vq[FPH];
+      float sq[FPH];
 #pragma unroll
-      for (int q = 0; q < FPH; ++q) { xq[q] = X[q]; vq[q] = Vv[q]; sq[q] = ST[q]; }
+      for (int q = 0; q < FPH; ++q) { xq[q] = X[r][q]; vq[q] = Vv[r][q]; sq[q] = SX[r][q]; }
 #pragma unroll
-      for (int q = 0; q < FPH; ++q) { S.load_xv(X[q], Vv[q], fr(j + 1, h + NH * q)); ST[q] = stats[fr(j + 1, h + NH * q)]; }
+      for (int q = 0; q < FPH; ++q) { S.load_xv(X[r][q], Vv[r][q], fr(j + PF2, h + NH * q)); SX[r][q] = stats[fr(j + PF2, h + NH * q)].x; }
 #pragma unroll
       for (int q = 0; q < FPH; ++q) {
         const int d = h + NH * q;
         if (d < nv) {
-          const float4 ev = S.expo(xq[q], sq[q].x);
+          const float4 ev = S.expo(xq[q], sq[q]);
           Emis<NL> e;
           S.gather(ev, vq[q], e);
           write_E<NL>(E[d], dump, lane, e);
@@ -937,23 +1022,62 @@ __device__ __forceinline__ void run_helper(const Problem &p, float4 *__restrict_
       }
     }
     block_barrier_raw();
+  };
+  for (int it0 = 0; it0 <= geo.NB + 2; it0 += PF2) {
+    static_for<0, PF2>([&](auto R) {
+      if (it0 + decltype(R)::value <= geo.NB + 2) body(R, it0 + decltype(R)::value);
+    });
   }
   if (massbad && lane == 0) atomicOr(&lds.flag, 64);  // D6
   __syncthreads();
 }
 
 // Wavefront roles: 0 main A, 1 main B, 2 recompute for A, 3 recompute for B, then NH helpers of A, NH helpers of B.
+// The log-domain pipeline for ONE utterance by the workgroup that flagged it (all eight wavefronts; ctc_hvp.hip for the stages).
 template <int KIND, int NL>
-__global__ __launch_bounds__(64 * NW) void hvp_fused_kernel(Problem p, float *__restrict__ rows_ws, int *__restrict__ kexp_ws, int nslot,
+__device__ __forceinline__ void redo_log_domain(const Problem &p, const Layout &L, char *ws, const float *__restrict__ vec,
+                                                float *__restrict__ loss, float *__restrict__ out, float *lds_f, int w, int b) {
+  const int lane = threadIdx.x & 63;
+  const HvpLayout H = make_hvp_layout(L, p.B, p.T);
+  float *emis = reinterpret_cast<float *>(ws + L.off_emis);
+  float *alpha = reinterpret_cast<float *>(ws + L.off_alpha);
+  float *beta = reinterpret_cast<float *>(ws + L.off_beta);
+  double *logp = reinterpret_cast<double *>(ws + L.off_logp);
+  char *ex = ws + L.off_extra;
+  float *demis = reinterpret_cast<float *>(ex + H.off_demis);
+  float *dalpha = reinterpret_cast<float *>(ex + H.off_dalpha);
+  float *dbeta = reinterpret_cast<float *>(ex + H.off_dbeta);
+  float *dlogp = reinterpret_cast<float *>(ex + H.off_dlogp);
+  // (every __syncthreads below drains the wavefront's stores first: rows written by one wavefront are read by another of the
+  // same CU through the shared L1, as at the meeting point of the chains)
+  for (int t = w; t < p.T; t += NW) emit_row(p, L, emis, b, t, lane);
+  __syncthreads();
+  if (w == 0) scan_body<KIND, NL, 0>(p, L, emis, alpha, logp, loss, b, lane);
+  else if (w == 1) scan_body<KIND, NL, 1>(p, L, emis, beta, logp, loss, b, lane);
+  else for (int t = w - 2; t < p.T; t += NW - 2) temit_row(p, L, emis, vec, demis, b, t, lane);  // (beside the value sweeps)
+  __syncthreads();
+  if (w < 2) tscan_body<KIND, NL>(p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp, b, w, lane);
+  __syncthreads();
+  float *bin = lds_f + w * (V + 4);
+  for (int t = w; t < p.T; t += NW) {
+    hvp_out_row<KIND>(p, L, emis, demis, alpha, beta, dalpha, dbeta, logp, dlogp, vec, out, bin, b, t, lane);
+    wave_lds_fence();  // the bins are reused by the next frame of this wavefront
+  }
+}
+
+template <int KIND, int NL>
+__global__ __launch_bounds__(64 * NW) void hvp_fused_kernel(Problem p, Layout L, char *__restrict__ ws_v1, float *__restrict__ rows_ws, int *__restrict__ kexp_ws, int nslot,
                                                              float4 *__restrict__ stats_ws, float *__restrict__ loss,
                                                              const float *__restrict__ vec, float *__restrict__ out,
-                                                             int *__restrict__ flag_ws) {
+                                                             int *__restrict__ flag_ws, int mode) {
+  // mode (timing diagnostics through ctc_amd_debug_override("hvp", "diag<mode>"), 0 in every product call): 1 = stop at the meeting
+  // point, 2 = the chains keep only their barriers in phase 2, 4 = the helpers do
   __shared__ __attribute__((aligned(16))) Lds<KIND, NL> lds;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x;
   Geo geo;
   geo.init(clampi(p.logit_length[b], 0, p.T));
-  if (threadIdx.x == 0) { lds.flag = 0; lds.feasible = 0; }
+  if (threadIdx.x == 0) { lds.flag = 0; lds.feasible = 0; lds.mode = mode; }
   if (threadIdx.x < NW) lds.l2s[threadIdx.x] = 0.0;
   __syncthreads();
   if (w == 0) {
@@ -973,6 +1097,11 @@ __global__ __launch_bounds__(64 * NW) void hvp_fused_kernel(Problem p, float *__
   } else {
     run_helper<KIND, NL, 1>(p, stats_ws, vec, out, lds, geo, w - 4 - NH, b);
   }
+  // utterances the linear domain cannot hold (normally none): redone right here in the log domain, every output row rewritten
+  __syncthreads();
+  const int fl = lds.mode ? 0 : lds.flag;
+  __syncthreads();  // (the LDS is reused from here on)
+  if (fl != 0) redo_log_domain<KIND, NL>(p, L, ws_v1, vec, loss, out, reinterpret_cast<float *>(&lds), w, b);
 }
 
 }  // namespace hvpf
@@ -982,9 +1111,12 @@ __global__ __launch_bounds__(64 * NW) void hvp_fused_kernel(Problem p, float *__
 #else
 #define CTC_HVPF_ENTRY run_hvp_fused_simplified
 #endif
-// ws_fused: the HvpFusedLayout region.  Leaves flags[b] != 0 for the utterances the caller has to redo in the log domain.
-hipError_t CTC_HVPF_ENTRY(const Problem &p, char *ws_fused, const float *vec, float *loss, float *out, hipStream_t st) {
+// ws: the CTC_AMD_WS_HVP workspace (L = its full-row layout: the regions of the log-domain building blocks; the fused kernel's
+// own region sits behind them).  flags[b] != 0 afterwards = utterance b was redone in the log domain (diagnostic).
+hipError_t CTC_HVPF_ENTRY(const Problem &p, const Layout &L, char *ws, const float *vec, float *loss, float *out, int mode, hipStream_t st) {
   const HvpFusedLayout H = make_hvp_fused_layout(p.B, p.T, p.U);
+  char *ws_fused = ws + L.off_extra + make_hvp_layout(L, p.B, p.T).total;
+  if (L.NL != (p.U <= 64 ? 1 : 2)) return hipErrorInvalidValue;
   float *rows = reinterpret_cast<float *>(ws_fused + H.off_rows);
   int *kexp = reinterpret_cast<int *>(ws_fused + H.off_kexp);
   float4 *stats = reinterpret_cast<float4 *>(ws_fused + H.off_stats);
@@ -993,9 +1125,9 @@ hipError_t CTC_HVPF_ENTRY(const Problem &p, char *ws_fused, const float *vec, fl
   static_assert(hvpf::V == HVPF_MAX_V && hvpf::Cfg<2>::UP == HVPF_MAX_U, "limits of ctc_hvp_fused.h");
   const dim3 grid(p.B), block(64 * hvpf::NW);
   if (p.U <= 64)
-    hipLaunchKernelGGL((hvpf::hvp_fused_kernel<CTC_FUSED_KIND, 1>), grid, block, 0, st, p, rows, kexp, H.nslot, stats, loss, vec, out, flags);
+    hipLaunchKernelGGL((hvpf::hvp_fused_kernel<CTC_FUSED_KIND, 1>), grid, block, 0, st, p, L, ws, rows, kexp, H.nslot, stats, loss, vec, out, flags, mode);
   else
-    hipLaunchKernelGGL((hvpf::hvp_fused_kernel<CTC_FUSED_KIND, 2>), grid, block, 0, st, p, rows, kexp, H.nslot, stats, loss, vec, out, flags);
+    hipLaunchKernelGGL((hvpf::hvp_fused_kernel<CTC_FUSED_KIND, 2>), grid, block, 0, st, p, L, ws, rows, kexp, H.nslot, stats, loss, vec, out, flags, mode);
   return hipGetLastError();
 }
 

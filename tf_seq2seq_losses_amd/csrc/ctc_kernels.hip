@@ -14,6 +14,7 @@
 #include "ctc_common.h"
 #include "ctc_amd.h"
 #include "ctc_swap_reduce.h"
+#include "ctc_v1_device.h"
 
 namespace ctc {
 
@@ -23,105 +24,12 @@ __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? l
 // ------------------------------------------------------------------------------------------------
 // emit
 // ------------------------------------------------------------------------------------------------
-// one frame (b, t) by one wavefront
-__device__ __forceinline__ void emit_row(const Problem &p, const Layout &L, float *__restrict__ emis, int b, int t, int lane) {
-  const long row = (long)b * p.T + t;
-  const int len = clampi(p.logit_length[b], 0, p.T);
-  if (t >= len) return;  // padded frames are never read downstream
-  const int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
-  const int V = p.V;
-  // element accessor of this frame's row: float32 or bfloat16, any batch/time stride (producer formats)
-  const long xoff = (long)b * p.xsb + (long)t * p.xst;
-  const float *x = p.logits + xoff;                                                   // valid for float32 only
-  const unsigned short *xh = reinterpret_cast<const unsigned short *>(p.logits) + xoff;  // valid for bfloat16 only
-  const bool bf = p.xdtype != 0;
-  auto xat = [&](int k) -> float { return bf ? bf16_to_f32(xh[k]) : x[k]; };
-
-  float mx = -INFINITY, sum = 0.f, log2sum = 0.f;
-  if (p.wrt == 0) {
-    if (!bf && ((V | xoff) & 3) == 0 && (p.align_bits & 15) == 0) {
-      // ONE pass over the row, eight 16-byte loads per lane in flight: every lane keeps a running (maximum, sum of
-      // exp(x - maximum)) of its own columns, the lanes are combined once at the end (two passes with one load in flight
-      // each read a V = 2048 row at 2.7 TB/s chip-wide)
-      float m = -INFINITY, s = 0.f;
-      for (int k0 = lane * 4; k0 < V; k0 += 256 * 8) {
-        float4 v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int k = k0 + 256 * q;
-          v[q] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-          if (k < V) v[q] = *reinterpret_cast<const float4 *>(x + k);
-        }
-        float cm = m;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) cm = fmaxf(fmaxf(cm, fmaxf(v[q].x, v[q].y)), fmaxf(v[q].z, v[q].w));
-        const float mr = (cm == -INFINITY) ? 0.f : cm;
-        s *= fexp2((m - mr) * LOG2E);  // (m = -inf: s is 0 and stays 0)
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          s += (fexp2((v[q].x - mr) * LOG2E) + fexp2((v[q].y - mr) * LOG2E)) + (fexp2((v[q].z - mr) * LOG2E) + fexp2((v[q].w - mr) * LOG2E));
-        m = cm;
-      }
-      mx = wave_max(m);
-      const float mref = (mx == -INFINITY) ? 0.f : mx;
-      sum = s * fexp2((m - mref) * LOG2E);
-      if (!(m > -INFINITY)) sum = 0.f;  // a lane whose columns are all -inf (or that holds none)
-    } else {
-      for (int k = lane; k < V; k += 64) mx = fmaxf(mx, xat(k));
-      mx = wave_max(mx);
-      const float mref = (mx == -INFINITY) ? 0.f : mx;
-      for (int k = lane; k < V; k += 64) sum += fexp2((xat(k) - mref) * LOG2E);
-    }
-    sum = wave_sum(sum);
-    log2sum = flog2(sum);  // -inf when the whole row is -inf: every emission becomes NEG below
-    if (mx == -INFINITY) mx = 0.f;
-  } else {
-    mx = 0.f;
-    log2sum = 0.f;
-  }
-  // log2 p(token k) = (x[k] - mx) * log2e - log2sum  (one rounding chain, no cancellation for huge logits)
-  float *erow = emis + row * (long)L.ERS;
-  for (int i = lane; i < L.UP; i += 64) {
-    float e = NEG;
-    if (i < ll) {
-      int tok = (i < p.label_stride) ? p.labels[(long)b * p.label_stride + i] : p.blank;
-      // (a label equal to the blank id is unsupported input in the reference; every tier treats it as an impossible
-      // emission: the sample comes out infeasible, loss +inf, gradient 0)
-      if (tok >= 0 && tok < V && tok != p.blank) e = fmaxf((xat(tok) - mx) * LOG2E - log2sum, NEG);
-      if (!(e == e)) e = NEG;
-    }
-    erow[i] = e;
-  }
-  if (lane == 0) {
-    float bl = NEG;
-    if (p.blank >= 0 && p.blank < V) bl = fmaxf((xat(p.blank) - mx) * LOG2E - log2sum, NEG);
-    if (!(bl == bl)) bl = NEG;
-    erow[L.UP] = bl;
-    // softmax(x)[k] = exp2((x[k] - mx) * log2e - log2sum); kept as two terms so that huge logits cancel exactly
-    erow[L.UP + 1] = mx;
-    erow[L.UP + 2] = log2sum;
-    erow[L.UP + 3] = 0.f;
-  }
-}
-
 __global__ __launch_bounds__(256) void emit_kernel(Problem p, Layout L, float *__restrict__ emis) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (row >= (long)p.B * p.T) return;
   emit_row(p, L, emis, (int)(row / p.T), (int)(row % p.T), lane);
 }
-// The frames of SELECTED utterances only (only_if[b] != 0: the utterances a fused kernel flagged for the log-domain pipeline,
-// normally none).  A small fixed grid walks the batch -- blockIdx.y strides over utterances, blockIdx.x over the frames of a
-// selected one -- so a call that selects nothing costs 2 048 workgroups that read 32 flags each, not B T / 4 empty ones.
-__global__ __launch_bounds__(256) void emit_sel_kernel(Problem p, Layout L, float *__restrict__ emis, const int *__restrict__ only_if) {
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int b = blockIdx.y; b < p.B; b += gridDim.y) {
-    if (only_if[b] == 0) continue;
-    for (int t = blockIdx.x * 4 + w; t < p.T; t += gridDim.x * 4) emit_row(p, L, emis, b, t, lane);
-  }
-}
-
 // Small vocabularies (V <= 512, float32, 16-byte aligned rows): FOUR consecutive frames of one utterance per wavefront.
 // One wavefront per row spent most of its time waiting -- a row is one or two 16-byte loads per lane, then two dependent
 // gathers (label -> token -> logit) per label position.  Here the rows' loads go out together, the four maxima and the four
@@ -212,290 +120,6 @@ __global__ __launch_bounds__(256) void emit4_kernel(Problem p, Layout L, float *
 // ------------------------------------------------------------------------------------------------
 // scan
 // ------------------------------------------------------------------------------------------------
-template <int NL>
-struct ERow {
-  float y[NL];
-  float bl;
-};
-
-template <int NL>
-__device__ __forceinline__ void load_erow(ERow<NL> &r, const float *__restrict__ base, int lane, int UP, int vz) {
-  const float *p = base + lane * NL;
-  if constexpr (NL == 1) {
-    r.y[0] = p[0];
-  } else if constexpr (NL == 2) {
-    float2 v = *reinterpret_cast<const float2 *>(p);
-    r.y[0] = v.x; r.y[1] = v.y;
-  } else {
-#pragma unroll
-    for (int q = 0; q < NL / 4; ++q) {
-      float4 v = *reinterpret_cast<const float4 *>(p + 4 * q);
-      r.y[4 * q] = v.x; r.y[4 * q + 1] = v.y; r.y[4 * q + 2] = v.z; r.y[4 * q + 3] = v.w;
-    }
-  }
-  // the blank emission is wave-uniform; fetched as a VECTOR load (vz = opaque zero): a scalar load returns out of
-  // order, so its use forces lgkmcnt(0), i.e. a wait for the youngest prefetch of the ring instead of the oldest
-  r.bl = base[UP + vz];
-}
-
-// store NL consecutive (a, b) pairs of this lane
-template <int NL>
-__device__ __forceinline__ void store_pairs(float *__restrict__ row, int lane, const float (&a)[NL], const float (&b)[NL]) {
-  float *p = row + 2 * lane * NL;
-  if constexpr (NL == 1) {
-    *reinterpret_cast<float2 *>(p) = make_float2(a[0], b[0]);
-  } else {
-#pragma unroll
-    for (int q = 0; q < NL / 2; ++q)
-      *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(a[2 * q], b[2 * q], a[2 * q + 1], b[2 * q + 1]);
-  }
-}
-template <int NL>
-__device__ __forceinline__ void store_singles(float *__restrict__ row, int lane, const float (&a)[NL]) {
-  float *p = row + lane * NL;
-  if constexpr (NL == 1) {
-    p[0] = a[0];
-  } else if constexpr (NL == 2) {
-    *reinterpret_cast<float2 *>(p) = make_float2(a[0], a[1]);
-  } else {
-#pragma unroll
-    for (int q = 0; q < NL / 4; ++q)
-      *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-  }
-}
-
-// emission rows kept in flight per wave (= steps of one unrolled block = steps between exact renormalisations of the
-// lattice row).  Fewer for long labels, whose rows fill the register file (16 rows of 16 positions per lane spilled
-// 1256 VGPRs).
-template <int NL>
-struct ScanCfg { static constexpr int PF = NL <= 2 ? 16 : (NL == 4 ? 8 : (NL == 8 ? 4 : 2)); };
-
-// One wavefront: blockIdx.x = utterance; DIR 0 = alpha (forward in t), 1 = beta (backward).
-// Slot i = lane*NL + j is label position i (token label[i]).
-//   classic alpha : c[j] = closed(l=i+1), o[j] = open(l=i+1), cx = closed(l=0)            (classic_ctc_loss.py:415-462)
-//   classic beta  : c[j] = closed(l=i),   o[j] = open(l=i+1), cx = closed(l=UP)           (classic_ctc_loss.py:349-377)
-//   simplified alpha: c[j] = a(l=i+1), cx = a(l=0); beta: c[j] = b(l=i), cx = b(l=UP)     (simplified_ctc_loss.py:327-438)
-// With y[i] = log p(label[i]) the classic transition tables of classic_ctc_loss.py:464-563 reduce to
-//   rep[l] = y[l-1],  yo[l] = y[l] unless label[l] == label[l-1]   (for labels free of the blank token).
-// The steady-state loop is straight-line code (PF steps unrolled, no branches) so that hipcc emits counted
-// s_waitcnt vmcnt(N): each step waits only for the emission row issued PF steps earlier, never for the
-// prefetches and row stores still in flight.
-template <int KIND, int NL, int DIR>
-struct Scan {
-  float c[NL], o[NL], cx;
-  double off;
-  bool norep[NL], norep_next[NL];
-
-  __device__ __forceinline__ void step(const ERow<NL> &e) {
-    const float bl = e.bl;
-    if constexpr (KIND == 0 && DIR == 0) {
-      // alpha step (classic_ctc_loss.py:415-451)
-      float m[NL], x[NL];
-#pragma unroll
-      for (int j = 0; j < NL; ++j) {
-        m[j] = lse2(c[j], o[j]);
-        x[j] = norep_next[j] ? m[j] : c[j];  // what position l+1 may continue from
-      }
-      float xin0 = from_prev_lane(x[NL - 1], cx);
-#pragma unroll
-      for (int j = NL - 1; j >= 0; --j) {
-        float xin = (j == 0) ? xin0 : x[j - 1];
-        o[j] = e.y[j] + lse2(o[j], xin);
-        c[j] = bl + m[j];
-      }
-      cx += bl;
-    } else if constexpr (KIND == 0 && DIR == 1) {
-      // beta step (classic_ctc_loss.py:349-364)
-      float h[NL], ee[NL], pn[NL], x[NL];
-#pragma unroll
-      for (int j = 0; j < NL; ++j) {
-        h[j] = bl + c[j];
-        ee[j] = e.y[j] + o[j];
-        pn[j] = lse2(h[j], ee[j]);
-        x[j] = norep[j] ? pn[j] : h[j];
-      }
-      cx += bl;
-      float xinl = from_next_lane(x[0], cx);
-#pragma unroll
-      for (int j = 0; j < NL; ++j) {
-        float xin = (j == NL - 1) ? xinl : x[j + 1];
-        o[j] = lse2(xin, ee[j]);
-        c[j] = pn[j];
-      }
-    } else if constexpr (KIND == 1 && DIR == 0) {
-      // simplified alpha step (simplified_ctc_loss.py:393-424)
-      float pin0 = from_prev_lane(c[NL - 1], cx);
-#pragma unroll
-      for (int j = NL - 1; j >= 0; --j) {
-        float pin = (j == 0) ? pin0 : c[j - 1];
-        c[j] = lse2(bl + c[j], e.y[j] + pin);
-      }
-      cx += bl;
-    } else {
-      // simplified beta step (simplified_ctc_loss.py:327-343)
-      float nin = from_next_lane(c[0], cx);
-#pragma unroll
-      for (int j = 0; j < NL; ++j) {
-        float nx = (j == NL - 1) ? nin : c[j + 1];
-        c[j] = lse2(bl + c[j], e.y[j] + nx);
-      }
-      cx += bl;
-    }
-  }
-
-  // exact renormalisation: subtract the row maximum, remember it in `off` (branch-free)
-  __device__ __forceinline__ void renorm() {
-    float mx = cx;
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      mx = fmaxf(mx, c[j]);
-      if constexpr (KIND == 0) mx = fmaxf(mx, o[j]);
-    }
-    mx = wave_max(mx);
-    mx = (mx > NEG_THR) ? mx : 0.f;
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      c[j] -= mx;
-      if constexpr (KIND == 0) o[j] -= mx;
-    }
-    cx -= mx;
-    off += (double)mx;
-  }
-
-  // row layout: see Layout in ctc_common.h.  The 16-byte tail (l = 0 state + offset) is wave-uniform data
-  // written by every lane to the same address, which keeps the store branch-free.
-  __device__ __forceinline__ void store_row(float *__restrict__ row, int lane, int UP) const {
-    const float oh = (float)off;
-    const float ol = (float)(off - (double)oh);
-    if constexpr (DIR == 0) {
-      if constexpr (KIND == 0) {
-        store_pairs<NL>(row, lane, c, o);
-        *reinterpret_cast<float4 *>(row + 2 * UP) = make_float4(cx, NEG, oh, ol);
-      } else {
-        store_singles<NL>(row, lane, c);
-        *reinterpret_cast<float4 *>(row + UP) = make_float4(cx, 0.f, oh, ol);
-      }
-    } else {
-      float cs[NL];  // state of label position l = i+1 lives in the next slot's c
-#pragma unroll
-      for (int j = 0; j < NL - 1; ++j) cs[j] = c[j + 1];
-      cs[NL - 1] = from_next_lane(c[0], cx);
-      const float c00 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c[0])));  // state l = 0 (lane 0, slot 0)
-      if constexpr (KIND == 0) {
-        store_pairs<NL>(row, lane, cs, o);
-        *reinterpret_cast<float4 *>(row + 2 * UP) = make_float4(c00, c00, oh, ol);
-      } else {
-        store_singles<NL>(row, lane, cs);
-        *reinterpret_cast<float4 *>(row + UP) = make_float4(c00, 0.f, oh, ol);
-      }
-    }
-  }
-};
-
-template <int KIND, int NL, int DIR>
-__device__ __forceinline__ void scan_body(const Problem &p, const Layout &L, const float *__restrict__ emis,
-                                          float *__restrict__ rows_all, double *__restrict__ logp,
-                                          float *__restrict__ loss) {
-  const int lane = threadIdx.x;
-  const int b = blockIdx.x;
-  const int T = p.T, UP = L.UP;
-  const int len = clampi(p.logit_length[b], 0, T);
-  int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
-  if (ll > p.U) {  // contract violation: reported as an infeasible sample
-    if (DIR == 0 && lane == 0) { logp[b] = -INFINITY; loss[b] = INFINITY; }
-    return;
-  }
-  Scan<KIND, NL, DIR> S;
-  S.off = 0.0;
-  {
-    const int32_t *lab = p.labels + (long)b * p.label_stride;
-    auto tok = [&](int i) -> int { return (i >= 0 && i < ll) ? ((i < p.label_stride) ? lab[i] : p.blank) : -1 - (i < 0); };
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      int i = lane * NL + j;
-      S.norep[j] = (i == 0) || tok(i) != tok(i - 1);
-      S.norep_next[j] = tok(i + 1) != tok(i);
-      S.c[j] = NEG;
-      S.o[j] = NEG;
-    }
-  }
-  float *rows = rows_all + (long)b * (T + 1) * L.SRS;
-  const float *ebase = emis + (long)b * T * L.ERS;
-
-  // ---- initial row ----
-  if constexpr (DIR == 0) {
-    S.cx = 0.f;  // alpha[0]: only (l=0, closed) is reachable (classic_ctc_loss.py:453-462, simplified_ctc_loss.py:426-438)
-  } else {
-    // beta[len]: one-hot at l = label_length, both states (classic_ctc_loss.py:366-377, simplified_ctc_loss.py:345-356)
-    S.cx = (ll == UP) ? 0.f : NEG;
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      int i = lane * NL + j;
-      if (i == ll) S.c[j] = 0.f;
-      if (KIND == 0 && i == ll - 1) S.o[j] = 0.f;
-    }
-  }
-  S.store_row(rows + (long)(DIR == 0 ? 0 : len) * L.SRS, lane, UP);
-
-  // step k consumes emission row t = k (alpha) / len-1-k (beta) and produces lattice row k+1 / len-1-k
-  auto erow_ptr = [&](int k) -> const float * {
-    int kk = k < len ? k : len - 1;
-    int t = (DIR == 0) ? kk : (len - 1 - kk);
-    return ebase + (long)t * L.ERS;
-  };
-  auto out_row = [&](int k) -> float * { return rows + (long)(DIR == 0 ? k + 1 : len - 1 - k) * L.SRS; };
-
-  if (len > 0) {
-    int vz;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
-    constexpr int PF = ScanCfg<NL>::PF, RENORM = PF;
-    ERow<NL> buf[PF];
-#pragma unroll
-    for (int d = 0; d < PF; ++d) load_erow<NL>(buf[d], erow_ptr(d), lane, UP, vz);
-    int k0 = 0;
-    for (; k0 + PF <= len; k0 += PF) {
-#pragma unroll
-      for (int d = 0; d < PF; ++d) {
-        S.step(buf[d]);
-        load_erow<NL>(buf[d], erow_ptr(k0 + d + PF), lane, UP, vz);  // clamped: re-reads the last row near the end
-        if (d == RENORM - 1) S.renorm();
-#ifndef CTC_EXPERIMENT_NO_STORE
-        S.store_row(out_row(k0 + d), lane, UP);
-#endif
-      }
-    }
-    // tail: fewer than PF steps left, their rows are already in buf[0 .. len-k0)
-#pragma unroll
-    for (int d = 0; d < PF; ++d) {
-      if (k0 + d < len) {
-        S.step(buf[d]);
-        S.store_row(out_row(k0 + d), lane, UP);
-      }
-    }
-  }
-
-  if constexpr (DIR == 0) {
-    // loss = -alpha[len, label_length] (classic_ctc_loss.py:152-165, simplified_ctc_loss.py:73-83)
-    float mine = NEG;
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      int i = lane * NL + j;
-      if (i == ll - 1) mine = (KIND == 0) ? lse2(S.c[j], S.o[j]) : S.c[j];
-    }
-    float v = (ll == 0) ? S.cx : wave_max(mine);
-    if (lane == 0) {
-      if (v > NEG_THR) {
-        double lp2 = (double)v + S.off;
-        logp[b] = lp2;
-        loss[b] = (float)(-lp2 * LN2_D);
-      } else {
-        logp[b] = -INFINITY;
-        loss[b] = INFINITY;
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // grad
 // ------------------------------------------------------------------------------------------------
@@ -912,39 +536,32 @@ namespace ctc {
 template <int KIND, int NL>
 __global__ __launch_bounds__(64) void scan_kernel(Problem p, Layout L, const float *__restrict__ emis,
                                                    float *__restrict__ alpha, float *__restrict__ beta,
-                                                   double *__restrict__ logp, float *__restrict__ loss, const int *__restrict__ only_if) {
-  if (only_if && only_if[blockIdx.x] == 0) return;  // (selected utterances only: see emit_sel_kernel)
-  if (blockIdx.y == 0) scan_body<KIND, NL, 0>(p, L, emis, alpha, logp, loss);
-  else scan_body<KIND, NL, 1>(p, L, emis, beta, logp, loss);
+                                                   double *__restrict__ logp, float *__restrict__ loss) {
+  if (blockIdx.y == 0) scan_body<KIND, NL, 0>(p, L, emis, alpha, logp, loss, blockIdx.x, threadIdx.x);
+  else scan_body<KIND, NL, 1>(p, L, emis, beta, logp, loss, blockIdx.x, threadIdx.x);
 }
 
 template <int KIND, int NL>
 static void launch_scan_nl(const Problem &p, const Layout &L, const float *emis, float *alpha, float *beta, double *logp,
-                           float *loss, int ndir, const int *only_if, hipStream_t st) {
-  hipLaunchKernelGGL((scan_kernel<KIND, NL>), dim3(p.B, ndir), dim3(64), 0, st, p, L, emis, alpha, beta, logp, loss, only_if);
+                           float *loss, int ndir, hipStream_t st) {
+  hipLaunchKernelGGL((scan_kernel<KIND, NL>), dim3(p.B, ndir), dim3(64), 0, st, p, L, emis, alpha, beta, logp, loss);
 }
 
 template <int KIND>
 static hipError_t launch_scan(const Problem &p, const Layout &L, const float *emis, float *alpha, float *beta,
-                              double *logp, float *loss, int ndir, const int *only_if, hipStream_t st) {
+                              double *logp, float *loss, int ndir, hipStream_t st) {
   switch (L.NL) {
-    case 1: launch_scan_nl<KIND, 1>(p, L, emis, alpha, beta, logp, loss, ndir, only_if, st); break;
-    case 2: launch_scan_nl<KIND, 2>(p, L, emis, alpha, beta, logp, loss, ndir, only_if, st); break;
-    case 4: launch_scan_nl<KIND, 4>(p, L, emis, alpha, beta, logp, loss, ndir, only_if, st); break;
-    case 8: launch_scan_nl<KIND, 8>(p, L, emis, alpha, beta, logp, loss, ndir, only_if, st); break;
-    case 16: launch_scan_nl<KIND, 16>(p, L, emis, alpha, beta, logp, loss, ndir, only_if, st); break;
+    case 1: launch_scan_nl<KIND, 1>(p, L, emis, alpha, beta, logp, loss, ndir, st); break;
+    case 2: launch_scan_nl<KIND, 2>(p, L, emis, alpha, beta, logp, loss, ndir, st); break;
+    case 4: launch_scan_nl<KIND, 4>(p, L, emis, alpha, beta, logp, loss, ndir, st); break;
+    case 8: launch_scan_nl<KIND, 8>(p, L, emis, alpha, beta, logp, loss, ndir, st); break;
+    case 16: launch_scan_nl<KIND, 16>(p, L, emis, alpha, beta, logp, loss, ndir, st); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-// grid of the selected-utterance kernels: frames along x, utterances strided along y
-dim3 sel_grid(int B, int T) {
-  const int gx = (T + 3) / 4 < 256 ? (T + 3) / 4 : 256;
-  return dim3(gx < 1 ? 1 : gx, B < 8 ? (B < 1 ? 1 : B) : 8);
-}
-
-hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *loss, int ndir, hipStream_t st, const int *only_if) {
+hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *loss, int ndir, hipStream_t st) {
   float *emis = reinterpret_cast<float *>(ws + L.off_emis);
   float *alpha = reinterpret_cast<float *>(ws + L.off_alpha);
   float *beta = reinterpret_cast<float *>(ws + L.off_beta);
@@ -953,15 +570,14 @@ hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *los
   if (rows > 0) {
     const bool four = p.V <= 512 && p.xdtype == 0 && (p.align_bits & 15) == 0 && ((p.V | p.xsb | p.xst) & 3) == 0;
     const long waves = (long)p.B * ((p.T + 3) / 4);
-    if (only_if) hipLaunchKernelGGL(emit_sel_kernel, sel_grid(p.B, p.T), dim3(256), 0, st, p, L, emis, only_if);
-    else if (four) hipLaunchKernelGGL(emit4_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, p, L, emis);
+    if (four) hipLaunchKernelGGL(emit4_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, p, L, emis);
     else hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, L, emis);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
   if (p.B == 0) return hipSuccess;
-  return p.kind == 0 ? launch_scan<0>(p, L, emis, alpha, beta, logp, loss, ndir, only_if, st)
-                     : launch_scan<1>(p, L, emis, alpha, beta, logp, loss, ndir, only_if, st);
+  return p.kind == 0 ? launch_scan<0>(p, L, emis, alpha, beta, logp, loss, ndir, st)
+                     : launch_scan<1>(p, L, emis, alpha, beta, logp, loss, ndir, st);
 }
 
 hipError_t run_grad(const Problem &p, const Layout &L, char *ws, const float *d_loss, float *grad, hipStream_t st) {
