@@ -220,7 +220,8 @@ int ctc_amd_loss_grad_ex(int kind, int wrt,
  * ctc_amd_loss_grad_ex that also accumulates what a training loop takes from the losses, without a launch of its own.
  * Replaces: tf.reduce_sum / reduce_mean of the loss over the finite samples (README.md:62, tests/benchmark.py:199).
  *   sum2[0] += sum over the finite loss[b] of round(loss[b] * 2^20)   (int64, fixed point: integer adds give the same
- *              bits whatever order the workgroups finish in -- and whatever order ranks are all-reduced in)
+ *              bits whatever order the workgroups finish in -- and whatever order ranks are all-reduced in; a single
+ *              loss beyond +-2^42 ~ 4.4e12 enters clamped to that, so that it cannot wrap the sum)
  *   sum2[1] += number of finite loss[b]
  *   sum2 must hold zeros on entry (or a running total the caller wants to extend); zero_next, if not NULL, points at the
  *   two int64 of the NEXT step and is cleared by this call -- alternate two buffers and nothing ever needs a memset.

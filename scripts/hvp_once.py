@@ -1,4 +1,4 @@
-"""Diagnostic: a few loss+grad calls at the north-star config (for rocprofv3 counter passes)."""
+"""Diagnostic: a few Hessian-vector products at the north-star config (for rocprofv3 counter passes)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,8 +7,8 @@ from tf_seq2seq_losses_amd import _lib, ops
 B, T, U, V = 256, 1000, 128, 256
 host, dev = bench.make_inputs(B, T, U, V, 0, False, torch.device("cuda:0"))
 prep = ops.Prepared(dev["labels"], dev["logits"], dev["label_length"], dev["logit_length"], 0, U=U)
-ws = torch.empty(_lib.workspace_bytes(_lib.WS_LOSS_GRAD_LOGITS, 0, B, T, V, U), dtype=torch.uint8, device="cuda:0")
+v = torch.randn((B, T, V), device="cuda:0")
 for _ in range(3):
-    loss, g = ops.loss_grad(0, _lib.WRT_LOGITS, prep, True, workspace=ws)
+    loss, _, out = ops.hvp(0, _lib.WRT_LOGITS, prep, v)
 torch.cuda.synchronize()
-print(float(loss.sum()))
+print(float(out.abs().max()))

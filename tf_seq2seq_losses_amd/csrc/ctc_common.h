@@ -107,9 +107,12 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 __device__ __forceinline__ float wave_max(float v) { return wave_max_dpp(v); }
 __device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 
-// [0] += v in units of 2^-20 (finite v only), [1] += 1: integer atomics, so the total does not depend on the order
+// [0] += v in units of 2^-20 (finite v only), [1] += 1: integer atomics, so the total does not depend on the order.
+// A finite loss beyond +-2^42 (a logit of 1e13) enters the sum clamped to that: 2^62 units, so that one such term cannot wrap
+// the int64 (include/ctc_amd.h, ctc_amd_loss_grad_sum).
 __device__ __forceinline__ void add_loss_fixed(long long *acc, float v, int sign = 1) {
   if ((v - v) == 0.f) {
+    v = fminf(fmaxf(v, -4398046511104.0f), 4398046511104.0f);
     atomicAdd(reinterpret_cast<unsigned long long *>(acc), (unsigned long long)((long long)sign * __float2ll_rn(v * 1048576.0f)));
     atomicAdd(reinterpret_cast<unsigned long long *>(acc) + 1, (unsigned long long)(long long)sign);
   }
