@@ -525,6 +525,10 @@ def main():
     # ... and, whatever --warmup says, at least 100 ms of the timed launch: a cold process ran its first ~25 launches 10 %
     # slow (r02: driver 174 us at --warmup 5 against 152-157 us at --warmup 20 on the same commit)
     extra_warm = prewarm(step, args.prewarm_ms) if args.prewarm_ms > 0 else 0
+    emu = EmulatedAllReduce(lib, device) if (args.emulate_collective and world == 1) else None
+    if emu is not None:  # (its stream, events and kernel exist before the timed region)
+        for _ in range(8):
+            emu(None).wait()
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
@@ -555,7 +559,6 @@ def main():
     # per step: ONE launch (loss + gradient + the [sum(loss), #finite] pair, ctc_amd_loss_grad_sum) + (N > 1) one asynchronous
     # all-reduce of the pair; the Hessian workload keeps the separate ctc_amd_reduce_loss launch
     seen = []
-    emu = EmulatedAllReduce(lib, device) if (args.emulate_collective and world == 1) else None
     cdist.pipelined_steps(timed_step, args.steps, reduced=in_kernel_sum, depth=args.pipeline_depth, all_reduce=emu,
                           consume=(lambda i, pair: seen.append(pair) if i == args.steps - 1 else None) if in_kernel_sum else None)
     ev1.record()
@@ -600,7 +603,6 @@ def main():
             pipeline = _lib.pipeline_name(kind, _lib.WRT_LOGITS, B, T, V, U, True)
             kernel_name = {"fused6": "fused6_kernel (one launch: linear-domain chains + recompute chains + helpers; flagged utterances are redone in the log domain inside it, none here)",
                            "fused5": "fused5_kernel (one launch: chains + recompute chains + helpers)",
-                           "fused2": "fused_kernel",
                            "v1": "emit_kernel + scan_kernel + grad_kernel"}[pipeline] + " = one ctc_amd_loss_grad call"
             # HBM bytes per launch from committed rocprofv3 PMC passes of this configuration (FETCH_SIZE x2 + WRITE_SIZE, see the
             # file's note).  Only quoted when the profiled kernel is the one this run launches (name with template arguments).

@@ -86,12 +86,12 @@ int ctc_amd_abi_version(void);
 const char *ctc_amd_last_error(void);
 
 /* Name of the kernel pipeline ctc_amd_loss_grad would run for contiguous float32 tensors of these shapes ("fused6",
- * "fused5", "fused2" or "v1"); diagnostic only (benchmarks and tests report it), never needed for correctness. */
+ * "fused5" or "v1"); diagnostic only (benchmarks and tests report it), never needed for correctness. */
 const char *ctc_amd_pipeline_name(int kind, int wrt, int B, int T, int V, int U, int want_grad);
 
 /*
  * Diagnostic override, for parity tests and benchmarks only (process-wide; set it between calls, not during one):
- *   key "pipeline": "" (best eligible tier, default), "v1", "fused2", "fused5" -- forces a lower tier of ctc_amd_loss_grad
+ *   key "pipeline": "" (best eligible tier, default), "v1", "fused5" -- forces a lower tier of ctc_amd_loss_grad
  *   key "hessian":  "" (default) or "slab" -- the general Hessian kernel also for labels of <= 32 positions
  *   key "hvp":      "" (default) or "v1"   -- the log-domain Hessian-vector pipeline also where the fused kernel applies
  * The library never reads the environment.  Returns CTC_AMD_EINVAL for an unknown key or value.

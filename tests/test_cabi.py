@@ -114,7 +114,7 @@ def test_limits_are_reported_not_crashed_into(lib):
 
 def test_debug_override_validation(lib):
     from tf_seq2seq_losses_amd import _lib
-    for key, val in (("pipeline", "v1"), ("pipeline", "fused2"), ("pipeline", "fused5"), ("pipeline", ""), ("hessian", "slab"), ("hessian", "")):
+    for key, val in (("pipeline", "v1"), ("pipeline", "fused5"), ("pipeline", ""), ("hessian", "slab"), ("hessian", "")):
         _lib.debug_override(key, val)
     assert _lib.pipeline_name(0, 0, 256, 1000, 256, 128) == "fused6"
     _lib.debug_override("pipeline", "fused5")

@@ -31,13 +31,12 @@ def _run(kind, logits, labels, ll, tl, pipeline, d_loss=None):
 def _check(kind, logits, labels, ll, tl, d_loss=None):
     l5, g5 = _run(kind, logits, labels, ll, tl, "fused5", d_loss)
     lf, gf = _run(kind, logits, labels, ll, tl, "", d_loss)  # default tier: fused6 (+ fused5 for what it flags)
-    l2, g2 = _run(kind, logits, labels, ll, tl, "fused2", d_loss)
     l1, g1 = _run(kind, logits, labels, ll, tl, "v1", d_loss)
     rl, rg = C.loss_grad(kind, labels, logits, ll, tl, 0)
     if d_loss is not None:
         rg = rg * d_loss[:, None, None]
     fin = np.isfinite(rl)
-    for lo, gr, name in ((l5, g5, "fused5"), (lf, gf, "fused6"), (l2, g2, "fused2"), (l1, g1, "v1")):
+    for lo, gr, name in ((l5, g5, "fused5"), (lf, gf, "fused6"), (l1, g1, "v1")):
         assert np.array_equal(np.isfinite(lo), fin), name
         assert np.all(lo[~fin] == np.inf), name
         if fin.any():
@@ -75,7 +74,7 @@ def test_fused_edge_lengths(kind):
     rl, rg = C.loss_grad(kind, labels, logits, ll, tl_ref, 0)
     rg = rg * d_loss[:, None, None]
     fin = np.isfinite(rl)
-    for pipeline in ("", "fused5", "fused2"):
+    for pipeline in ("", "fused5", "v1"):
         lf, gf = _run(kind, logits, labels, ll, tl, pipeline, d_loss)
         assert np.array_equal(np.isfinite(lf), fin), pipeline
         assert (np.abs(lf[fin] - rl[fin]) / np.maximum(1, np.abs(rl[fin]))).max() < TOL, pipeline

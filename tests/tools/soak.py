@@ -4,7 +4,7 @@ float64 C oracle on a subsample; prints a progress line every few seconds.
 Every checked utterance falls into one class, read from the kernel's own flag word (ctc_amd_debug_flags_offset):
   linear   computed by the linear-domain fused kernel (flag 0)         bound 1e-4 (north_star's tolerance)
   redone   flagged by it and redone by the log-domain roles            bound 2e-3 (float32 log-domain recursion)
-  other    pipelines without flags (fused5 forced / fused2 / v1)       bound 2e-4, 2e-3 when |loss| > 500
+  other    pipelines without flags (fused5 forced / v1)       bound 2e-4, 2e-3 when |loss| > 500
 The worst error is reported per class."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

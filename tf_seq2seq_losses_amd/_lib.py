@@ -104,7 +104,7 @@ def pipeline_name(kind: int, wrt: int, B: int, T: int, V: int, U: int, want_grad
 
 
 def debug_override(key: str, value: str = "") -> None:
-    """Diagnostic (parity tests, benchmarks): force a lower kernel tier ("pipeline": "v1" | "fused2" | "fused5") or the
+    """Diagnostic (parity tests, benchmarks): force a lower kernel tier ("pipeline": "v1" | "fused5") or the
     general Hessian kernel ("hessian": "slab"); the empty string restores the default.  Process-wide."""
     global override_generation
     check(load().ctc_amd_debug_override(key.encode(), value.encode()), "ctc_amd_debug_override")

@@ -14,8 +14,6 @@ hipError_t run_grad(const Problem &p, const Layout &L, char *ws, const float *d_
 hipError_t run_sum_loss_fixed(const float *loss, int B, long long *acc, long long *zero_next, hipStream_t st);
 hipError_t run_log_posterior(const Problem &p, const Layout &L, char *ws, float *out, hipStream_t st);
 hipError_t run_convert(const Problem &p, const Layout &L, char *ws, float *alpha_out, float *beta_out, hipStream_t st);
-hipError_t run_fused_classic(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
-hipError_t run_fused_simplified(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
 #define CTC_F5_DECL(name) hipError_t name(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, bool only_flagged, hipStream_t st)
 CTC_F5_DECL(run_fused5_classic_nl1); CTC_F5_DECL(run_fused5_classic_nl2); CTC_F5_DECL(run_fused5_classic_nl4); CTC_F5_DECL(run_fused5_classic_nl8);
 CTC_F5_DECL(run_fused5_simplified_nl1); CTC_F5_DECL(run_fused5_simplified_nl2); CTC_F5_DECL(run_fused5_simplified_nl4); CTC_F5_DECL(run_fused5_simplified_nl8);
@@ -59,18 +57,11 @@ inline hipError_t run_fused6(const Problem &p, const Layout &L, char *ws, float 
   }
   return e;  // (flagged utterances are redone in the log domain inside the same launch: ctc_fused6.hip, end of fused6_kernel)
 }
-// shapes the two-wavefront fused kernel (ctc_fused.hip) is instantiated for: logits input, V in {256, 512, 1024}, U <= 256
-inline bool fused_eligible(const Problem &p, const Layout &L) {
-  return (p.align_bits & 15) == 0 && p.wrt == 0 && (p.V == 256 || p.V == 512 || p.V == 1024) && L.NL <= 4 && p.B > 0 && p.T > 0 && plain_format(p);
-}
-inline hipError_t run_fused(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st) {
-  return p.kind == 0 ? run_fused_classic(p, L, ws, loss, d_loss, grad, st) : run_fused_simplified(p, L, ws, loss, d_loss, grad, st);
-}
 size_t hessian_extra_bytes(int kind, int B, int T, int V, int U);
 hipError_t run_hessian(const Problem &p, const Layout &L, char *ws, const float *grad, float *hess, hipStream_t st);
 size_t hvp_extra_bytes(int kind, int B, int T, int V, int U);
 // diagnostic overrides (ctc_amd_debug_override): process-wide, written only by tests / benchmarks between calls
-int g_force_pipeline = 0;      // 0 = best eligible tier, 1 = v1, 2 = fused2, 5 = fused5 (log domain)
+int g_force_pipeline = 0;      // 0 = best eligible tier, 1 = v1, 5 = fused5 (log domain)
 int g_force_hessian_slab = 0;  // 1 = the general one-slab-per-wavefront Hessian kernel also for short labels
 int g_force_hvp_v1 = 0;        // 1 = the log-domain Hessian-vector pipeline also where the fused kernel applies
 int g_hvp_diag = 0;            // timing diagnostics of the fused kernel (ctc_hvp_fused.hip `mode`; results are then meaningless)
@@ -142,15 +133,15 @@ const char *ctc_amd_last_error(void) { return g_err; }
 static const char *select_pipeline(const ctc::Problem &p, const ctc::Layout &L, bool want_grad) {
   // pipeline selection by shape eligibility: fused6 (ctc_fused6.hip: linear-domain chains + recompute chains + helpers,
   // followed by a fused5 launch for the utterances it flags) = fused5 (ctc_fused5.hip: the same decomposition in the log
-  // domain) > fused2 (ctc_fused.hip: two self-contained wavefronts) > v1 (emit -> scan -> grad).  A lower tier can be
-  // forced through ctc_amd_debug_override (the parity tests run all of them); nothing here reads the environment.
+  // domain) > v1 (emit -> scan -> grad; r01's two-wavefront "fused2" tier is gone: it served one corner, V = 1024 with
+  // 128 < U <= 256, which the three-kernel pipeline now takes).  A lower tier can be forced through ctc_amd_debug_override
+  // (the parity tests run all of them); nothing here reads the environment.
   const int forced = ctc::g_force_pipeline;
   if (forced == 1) return "v1";
-  // loss only (grad == NULL): fused5 / fused6 stop at the meeting point of their two chains; fused2 needs a gradient
+  // loss only (grad == NULL): fused5 / fused6 stop at the meeting point of their two chains
+  (void)want_grad;
   if (forced == 0 && ctc::fused6_eligible(p, L)) return "fused6";
   if ((forced == 0 || forced == 5) && ctc::fused5_eligible(p, L)) return "fused5";
-  if (!want_grad) return "v1";
-  if (ctc::fused_eligible(p, L)) return "fused2";
   return "v1";
 }
 
@@ -164,8 +155,8 @@ static ctc::Layout layout_for(const ctc::Problem &p, const char *pl) {
 int ctc_amd_debug_override(const char *key, const char *value) {
   if (!key || !value) return fail(CTC_AMD_EINVAL, "null key/value");
   if (!strcmp(key, "pipeline")) {
-    const int f = !strcmp(value, "") ? 0 : !strcmp(value, "v1") ? 1 : !strcmp(value, "fused2") ? 2 : !strcmp(value, "fused5") ? 5 : -1;
-    if (f < 0) return fail(CTC_AMD_EINVAL, "pipeline override must be \"\", \"v1\", \"fused2\" or \"fused5\", got \"%s\"", value);
+    const int f = !strcmp(value, "") ? 0 : !strcmp(value, "v1") ? 1 : !strcmp(value, "fused5") ? 5 : -1;
+    if (f < 0) return fail(CTC_AMD_EINVAL, "pipeline override must be \"\", \"v1\" or \"fused5\", got \"%s\"", value);
     ctc::g_force_pipeline = f;
     return CTC_AMD_OK;
   }
@@ -279,8 +270,7 @@ static int loss_grad_impl(ctc::Problem p, float *loss, void *grad, const float *
   if (pl[0] == 'f') {
     char *wsb = static_cast<char *>(workspace);
     hipError_t ef = (pl[5] == '6') ? ctc::run_fused6(p, L, wsb, loss, d_loss, gradf, st)
-                  : (pl[5] == '5') ? ctc::run_fused5(p, L, wsb, loss, d_loss, gradf, false, st)
-                                   : ctc::run_fused(p, L, wsb, loss, d_loss, gradf, st);
+                                   : ctc::run_fused5(p, L, wsb, loss, d_loss, gradf, false, st);
     if (ef != hipSuccess) return hip_fail(ef, pl);
     if (p.sum_out && pl[5] != '6') {  // (fused6 adds inside its launch)
       ef = ctc::run_sum_loss_fixed(loss, p.B, p.sum_out, p.sum_zero, st);
