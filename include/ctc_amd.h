@@ -105,6 +105,9 @@ int ctc_amd_debug_override(const char *key /*host*/, const char *value /*host*/)
  * Returns CTC_AMD_EINVAL when that call would not run the "fused6" pipeline.
  */
 int ctc_amd_debug_flags_offset(int kind, int B, int T, int V, int U, size_t *out_offset /*host*/);
+/* The same for the fused Hessian-vector kernel: offset of its int32[B] flag words inside a CTC_AMD_WS_HVP workspace
+ * (CTC_AMD_EINVAL for shapes ctc_amd_hvp does not run that kernel for). */
+int ctc_amd_debug_hvp_flags_offset(int kind, int B, int T, int V, int U, size_t *out_offset /*host*/);
 
 /*
  * out2[0] = sum of the finite entries of loss[B], out2[1] = their number (as float): the two scalars a data-parallel

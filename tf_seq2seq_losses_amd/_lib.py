@@ -33,6 +33,7 @@ SIGNATURES = {
     "ctc_amd_pipeline_name": (ctypes.c_char_p, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "ctc_amd_debug_override": (_c_int, [ctypes.c_char_p, ctypes.c_char_p]),
     "ctc_amd_debug_flags_offset": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_size_t)]),
+    "ctc_amd_debug_hvp_flags_offset": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_size_t)]),
     "ctc_amd_reduce_loss": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),
     "ctc_amd_probe_copy": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "ctc_amd_probe_spin": (_c_int, [_c_int, _c_int, ctypes.c_float, _c_void_p]),
@@ -115,6 +116,13 @@ def flags_offset(kind: int, B: int, T: int, V: int, U: int) -> int:
     """Diagnostic: where the linear-domain kernel's per-utterance flag words sit in a logits call's workspace."""
     out = _c_size_t(0)
     check(load().ctc_amd_debug_flags_offset(kind, B, T, V, U, ctypes.byref(out)), "ctc_amd_debug_flags_offset")
+    return int(out.value)
+
+
+def hvp_flags_offset(kind: int, B: int, T: int, V: int, U: int) -> int:
+    """Diagnostic: where the fused Hessian-vector kernel's per-utterance flag words sit in a WS_HVP workspace."""
+    out = _c_size_t(0)
+    check(load().ctc_amd_debug_hvp_flags_offset(kind, B, T, V, U, ctypes.byref(out)), "ctc_amd_debug_hvp_flags_offset")
     return int(out.value)
 
 

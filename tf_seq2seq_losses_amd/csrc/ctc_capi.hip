@@ -60,6 +60,7 @@ inline hipError_t run_fused6(const Problem &p, const Layout &L, char *ws, float 
 size_t hessian_extra_bytes(int kind, int B, int T, int V, int U);
 hipError_t run_hessian(const Problem &p, const Layout &L, char *ws, const float *grad, float *hess, hipStream_t st);
 size_t hvp_extra_bytes(int kind, int B, int T, int V, int U);
+size_t hvp_fused_flags_offset(int kind, int B, int T, int U);
 // diagnostic overrides (ctc_amd_debug_override): process-wide, written only by tests / benchmarks between calls
 int g_force_pipeline = 0;      // 0 = best eligible tier, 1 = v1, 5 = fused5 (log domain)
 int g_force_hessian_slab = 0;  // 1 = the general one-slab-per-wavefront Hessian kernel also for short labels
@@ -193,6 +194,14 @@ int ctc_amd_debug_flags_offset(int kind, int B, int T, int V, int U, size_t *out
   const char *pl = select_pipeline(p, ctc::make_layout(kind, B, T, U, 0), true);
   if (strcmp(pl, "fused6")) return fail(CTC_AMD_EINVAL, "these shapes run the %s pipeline, which keeps no flags", pl);
   *out_offset = layout_for(p, pl).off_flags;
+  return CTC_AMD_OK;
+}
+
+int ctc_amd_debug_hvp_flags_offset(int kind, int B, int T, int V, int U, size_t *out_offset) {
+  if (!out_offset) return fail(CTC_AMD_EINVAL, "out_offset is null");
+  if ((kind != 0 && kind != 1) || B < 0 || T < 0 || V <= 0 || U < 0 || U > MAX_U) return fail(CTC_AMD_EINVAL, "bad shape");
+  if (!ctc::hvp_fused_shape(CTC_AMD_WRT_LOGITS, B, T, V, U)) return fail(CTC_AMD_EINVAL, "these shapes run the log-domain Hessian-vector pipeline, which keeps no flags");
+  *out_offset = ctc::make_layout(kind, B, T, U, 0).off_extra + ctc::hvp_fused_flags_offset(kind, B, T, U);
   return CTC_AMD_OK;
 }
 

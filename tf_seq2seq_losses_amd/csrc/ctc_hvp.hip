@@ -24,6 +24,11 @@ namespace ctc {
 
 using namespace ctc::fused;
 
+// offset (inside the extra part of the workspace) of the fused kernel's flag words: diagnostics
+size_t hvp_fused_flags_offset(int kind, int B, int T, int U) {
+  Layout L = make_layout(kind, B, T, U, 0);
+  return make_hvp_layout(L, B, T).total + make_hvp_fused_layout(B, T, U).off_flags;
+}
 size_t hvp_extra_bytes(int kind, int B, int T, int V, int U) {
   Layout L = make_layout(kind, B, T, U, 0);
   // (the fused kernel's region sits behind the log-domain pipeline's: the latter still serves the utterances the former flags)

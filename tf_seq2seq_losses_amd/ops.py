@@ -321,8 +321,10 @@ def hessian(kind: int, wrt: int, p: Prepared, want_grad: bool = True):
     return loss, grad, hess
 
 
-def hvp(kind: int, wrt: int, p: Prepared, vec: torch.Tensor, want_grad: bool = False):
-    """out[b,t,k] = sum_{t2,k2} H[b,t,k,t2,k2] vec[b,t2,k2] through ctc_amd_hvp (no [B,T,V,T,V] tensor)."""
+def hvp(kind: int, wrt: int, p: Prepared, vec: torch.Tensor, want_grad: bool = False, return_workspace: bool = False):
+    """out[b,t,k] = sum_{t2,k2} H[b,t,k,t2,k2] vec[b,t2,k2] through ctc_amd_hvp (no [B,T,V,T,V] tensor).
+    return_workspace (diagnostics): also the workspace, whose flag words say which utterances the fused kernel redid in the log
+    domain (_lib.hvp_flags_offset)."""
     lib = _lib.load()
     p = p.plain()
     assert tuple(vec.shape) == (p.B, p.T, p.V), f"vec must be [B,T,V] = {(p.B, p.T, p.V)}, got {tuple(vec.shape)}"
@@ -339,6 +341,8 @@ def hvp(kind: int, wrt: int, p: Prepared, vec: torch.Tensor, want_grad: bool = F
         rc = lib.ctc_amd_hvp(*p.common(kind, wrt), _ptr(vec), _ptr(loss), _ptr(grad), _ptr(out),
                              ws.data_ptr(), ws.numel(), _stream(p.device))
     _lib.check(rc, "ctc_amd_hvp")
+    if return_workspace:
+        return loss, grad, out, ws
     return loss, grad, out
 
 
