@@ -186,9 +186,9 @@ class EmulatedAllReduce:
         def wait(self):
             torch.cuda.current_stream().wait_event(self.ev)
 
-    def __init__(self, lib, device, us=12.0, threads=512, lds=4096):
+    def __init__(self, lib, device, us=12.0, threads=512, lds=4096, priority=0):
         self.lib, self.us, self.threads, self.lds = lib, us, threads, lds
-        self.side = torch.cuda.Stream(device=device)
+        self.side = torch.cuda.Stream(device=device, priority=priority)
 
     def __call__(self, buf):
         ready = torch.cuda.Event()
