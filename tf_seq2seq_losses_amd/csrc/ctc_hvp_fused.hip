@@ -24,7 +24,7 @@
 // it meets, and a batch in which every utterance is flagged costs what the five-launch pipeline costs.
 //
 // Instantiated for logits input, contiguous float32 [B,T,V] with V <= 256 (V % 4 == 0) and U <= 128 (one or two label positions
-// per lane): 8 wavefronts, 6-frame blocks, 143 KB of LDS.  Other shapes keep the log-domain pipeline.
+// per lane): 10 wavefronts, 6-frame blocks, 150 KB of LDS.  Other shapes keep the log-domain pipeline.
 #include "ctc_fused_common.h"
 #include "ctc_swap_reduce.h"
 #include "ctc_hvp_fused.h"
@@ -40,7 +40,7 @@ namespace hvpf {
 
 using namespace ctc::fused;
 
-constexpr int BLK = HVPF_BLK, NH = 2, RN = 3, NG = BLK / RN, NW = 4 + 2 * NH, FPH = BLK / NH;
+constexpr int BLK = HVPF_BLK, NH = 3, RN = 3, NG = BLK / RN, NW = 4 + 2 * NH;  // 10 wavefronts: 4 chains + 3 helpers a side
 constexpr int V = 256;
 constexpr int DEAD = -(1 << 24);
 constexpr int GAP = 16, GAP_WIDE = 64;
@@ -808,13 +808,13 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const float *__r
   const float *ck_rows = rows_ws + ((long)b * 2 + RDIR) * nslot * RS;
   const int *ck_k = kexp_ws + ((long)b * 2 + RDIR) * nslot * 64;
   float *dump = lds.dump[2 + SIDE];
-  {  // phase 1: E-stage frames 4, 5 of every block of this side
+  {  // phase 1: E-stage position 5 of every block of this side
     Rows<KIND, NL> W;
     W.init(p, b, lane, ll, vec, nullptr);
     W.xs = lds.xcopy[2 * NH + SIDE];
     W.vs = lds.vcopy[2 * NH + SIDE];
     if (lane == 0) { W.xs[V] = 0.f; W.vs[V] = 0.f; }
-    estage1<KIND, NL, SIDE, 2 * (BLK / 3), BLK - 2 * (BLK / 3)>(W, lds, geo, stats_ws + (long)b * p.T, dump, lane, 2 + SIDE);
+    estage1<KIND, NL, SIDE, BLK - 1, 1>(W, lds, geo, stats_ws + (long)b * p.T, dump, lane, 2 + SIDE);
     __syncthreads();
     __syncthreads();
   }
@@ -891,34 +891,38 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const float *__r
 }
 
 // ------------------------------------------------------------------------------------------------
-// helper wavefront h of NH per side: positions h, h + NH, h + 2 NH of every block
+// helper wavefront `slot` of side DIR, three per side, two positions of every block each in phase 2 (P2, P2 + 1).  The G stage
+// is a long dependent sequence per frame (S row -> three reductions -> bins -> atomics -> bins -> row), so the helpers are bound
+// by frames per wavefront, not by issue slots: two helpers a side with three frames each took 2.4 us per block, an uneven 2 / 4
+// split (light helper beside the main chain) 2.6.  Phase 1: positions P1 .. P1 + N1 - 1 (2, 2, 1; the recompute wavefront,
+// idle as a chain then, takes the sixth).
 // ------------------------------------------------------------------------------------------------
-template <int KIND, int NL, int DIR>
+template <int KIND, int NL, int DIR, int P1, int N1, int P2, int N2>
 __device__ __forceinline__ void run_helper(const Problem &p, float4 *__restrict__ stats_ws, const float *__restrict__ vec, float *__restrict__ out,
-                                           Lds<KIND, NL> &lds, const Geo &geo, int h, int b) {
+                                           Lds<KIND, NL> &lds, const Geo &geo, int slot, int b) {
   using C = Cfg<NL>;
+  static_assert(N2 >= 1 && N2 <= 4, "at most four positions per block (one four-value reduction)");
   Rows<KIND, NL> S;
   const int lane = threadIdx.x & 63;
   const int len = geo.len;
   int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
   if (ll > p.U || ll > C::UP) ll = 0;
   S.init(p, b, lane, ll, vec, out);
-  S.xs = lds.xcopy[DIR * NH + h];
-  S.vs = lds.vcopy[DIR * NH + h];
-  S.bins = lds.bins[DIR * NH + h];
+  S.xs = lds.xcopy[DIR * NH + slot];
+  S.vs = lds.vcopy[DIR * NH + slot];
+  S.bins = lds.bins[DIR * NH + slot];
   if (lane == 0) { S.xs[V] = 0.f; S.vs[V] = 0.f; }
   float4 *stats = stats_ws + (long)b * p.T;
-  float *dump = lds.dump[4 + DIR * NH + h];
-  const int wave = 4 + DIR * NH + h;
+  float *dump = lds.dump[4 + DIR * NH + slot];
+  const int wave = 4 + DIR * NH + slot;
   // ================= phase 1 =================
-  if (h == 0) estage1<KIND, NL, DIR, 0, BLK / 3>(S, lds, geo, stats, dump, lane, wave);
-  else estage1<KIND, NL, DIR, BLK / 3, BLK / 3>(S, lds, geo, stats, dump, lane, wave);
+  estage1<KIND, NL, DIR, P1, N1>(S, lds, geo, stats, dump, lane, wave);
   __syncthreads();
   __syncthreads();
   if (lds.feasible == 0) return;
   // ================= phase 2: E stage of block it, G stage of block it-3 =================
   const int nb = geo.nblocks(2, DIR);
-  if (h == 0 && DIR == 0) S.zero_rows(len, p.T);  // frames beyond logit_length: the Hessian vanishes there (base_loss.py:240-258)
+  if (slot == 0 && DIR == 0) S.zero_rows(len, p.T);  // frames beyond logit_length: the Hessian vanishes there (base_loss.py:240-258)
   auto fr = [&](int j, int d) -> int {
     int jj = j < nb ? j : nb - 1;
     jj = jj < 0 ? 0 : jj;
@@ -929,45 +933,47 @@ __device__ __forceinline__ void run_helper(const Problem &p, float4 *__restrict_
     t = t < len ? t : len - 1;
     return t < 0 ? 0 : t;
   };
-  // E-stage rows: a ring of PF2 register sets, loaded PF2 blocks ahead (see estage1); the G stage reads its rows again (they
-  // come from L2: the E stage had them three blocks earlier)
-  constexpr int PF2 = 3;
-  float4 X[PF2][FPH], Vv[PF2][FPH];
-  float SX[PF2][FPH];
+  // Two register rings addressed at compile time (the loop is unrolled by 2): E-stage rows loaded 2 blocks ahead, G-stage rows
+  // (the same rows, needed again three blocks later: read once more, mostly from L2) loaded ONE iteration ahead -- loaded at the
+  // top of the iteration that uses them they cost the helpers ~1.5 us of waiting per block.
+  constexpr int PF2 = 2;
+  float4 X[PF2][N2], Vv[PF2][N2];
+  float SX[PF2][N2];
+  float4 XG[2][N2], VG[2][N2], SG[2][N2];
   static_for<0, PF2>([&](auto R) {
     constexpr int r = decltype(R)::value;
 #pragma unroll
-    for (int q = 0; q < FPH; ++q) {
+    for (int q = 0; q < N2; ++q) {
       X[r][q] = make_float4(0.f, 0.f, 0.f, 0.f); Vv[r][q] = X[r][q]; SX[r][q] = 0.f;
-      if (nb > 0) { S.load_xv(X[r][q], Vv[r][q], fr(r, h + NH * q)); SX[r][q] = stats[fr(r, h + NH * q)].x; }
+      XG[r][q] = X[r][q]; VG[r][q] = X[r][q]; SG[r][q] = X[r][q];
+      if (nb > 0) { S.load_xv(X[r][q], Vv[r][q], fr(r, P2 + q)); SX[r][q] = stats[fr(r, P2 + q)].x; }
     }
   });
   bool massbad = false;
   const bool idle = (lds.mode & 4) != 0;
   auto body = [&](auto R, int it) __attribute__((always_inline)) {
-    constexpr int r = decltype(R)::value;  // = it mod PF2
+    constexpr int r = decltype(R)::value;  // = it mod 2
     if (idle) { block_barrier_raw(); return; }
-    // rows of the G stage's block (read again)
-    float4 XG[FPH], VG[FPH], SG[FPH];
     const int gj = it - 3;
     const bool do_g = gj >= 0 && gj < nb;
+    // rows of the NEXT iteration's G block (block it-2) into the other set
 #pragma unroll
-    for (int q = 0; q < FPH; ++q) { S.load_xv(XG[q], VG[q], fr(gj, h + NH * q)); SG[q] = stats[fr(gj, h + NH * q)]; }
+    for (int q = 0; q < N2; ++q) { S.load_xv(XG[1 - r][q], VG[1 - r][q], fr(gj + 1, P2 + q)); SG[1 - r][q] = stats[fr(gj + 1, P2 + q)]; }
     // ---- E stage (block it) ----
     const int j = it;
     if (j < nb) {
       const int g = geo.absblock(2, DIR, j);
       const int nv = geo.nvof(g);
       float(*E)[C::ES] = lds.E[DIR][j % 3];
-      float4 xq[FPH], vq[FPH];
-      float sq[FPH];
+      float4 xq[N2], vq[N2];
+      float sq[N2];
 #pragma unroll
-      for (int q = 0; q < FPH; ++q) { xq[q] = X[r][q]; vq[q] = Vv[r][q]; sq[q] = SX[r][q]; }
+      for (int q = 0; q < N2; ++q) { xq[q] = X[r][q]; vq[q] = Vv[r][q]; sq[q] = SX[r][q]; }
 #pragma unroll
-      for (int q = 0; q < FPH; ++q) { S.load_xv(X[r][q], Vv[r][q], fr(j + PF2, h + NH * q)); SX[r][q] = stats[fr(j + PF2, h + NH * q)].x; }
+      for (int q = 0; q < N2; ++q) { S.load_xv(X[r][q], Vv[r][q], fr(j + PF2, P2 + q)); SX[r][q] = stats[fr(j + PF2, P2 + q)].x; }
 #pragma unroll
-      for (int q = 0; q < FPH; ++q) {
-        const int d = h + NH * q;
+      for (int q = 0; q < N2; ++q) {
+        const int d = P2 + q;
         if (d < nv) {
           const float4 ev = S.expo(xq[q], sq[q]);
           Emis<NL> e;
@@ -983,11 +989,11 @@ __device__ __forceinline__ void run_helper(const Problem &p, float4 *__restrict_
       const float(*SR)[C::RS] = lds.R[DIR][gj % 3];
       const float(*KLr)[64] = lds.kl[DIR][gj % 3];
       constexpr int JS = (KIND == 1) ? (DIR == 0 ? NL - 1 : 0) : -1;  // simplified: the slot whose token part is already scaled
-      float dqt[FPH][NL];
+      float dqt[N2][NL];
       float qm[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, as[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < FPH; ++q) {
-        const int d = h + NH * q;
+      for (int q = 0; q < N2; ++q) {
+        const int d = P2 + q;
         const int dd = d < nv ? d : nv - 1;
         const float *srow = SR[dd] + 4 * lane * NL;
         const float kl = KLr[dd][lane];
@@ -1011,20 +1017,20 @@ __device__ __forceinline__ void run_helper(const Problem &p, float4 *__restrict_
       }
       const float qall = swap_reduce<4, false>(qm), dball = swap_reduce<4, false>(db), aall = swap_reduce<4, false>(as);
 #pragma unroll
-      for (int q = 0; q < FPH; ++q) {
-        const int d = h + NH * q;
+      for (int q = 0; q < N2; ++q) {
+        const int d = P2 + q;
         if (d < nv) {
           massbad |= !(fabsf(readlane_f(qall, SwapLanes<4>::lane(q)) - 1073741824.0f) < 1073741824.0f * 1e-4f);  // D6
-          const float4 ev = S.expo(XG[q], SG[q].x);
-          S.out_row(geo.frame(DIR, g, d), readlane_f(dball, SwapLanes<4>::lane(q)), dqt[q], readlane_f(aall, SwapLanes<4>::lane(q)), ev, VG[q],
-                    SG[q].y, SG[q].z);
+          const float4 ev = S.expo(XG[r][q], SG[r][q].x);
+          S.out_row(geo.frame(DIR, g, d), readlane_f(dball, SwapLanes<4>::lane(q)), dqt[q], readlane_f(aall, SwapLanes<4>::lane(q)), ev, VG[r][q],
+                    SG[r][q].y, SG[r][q].z);
         }
       }
     }
     block_barrier_raw();
   };
-  for (int it0 = 0; it0 <= geo.NB + 2; it0 += PF2) {
-    static_for<0, PF2>([&](auto R) {
+  for (int it0 = 0; it0 <= geo.NB + 2; it0 += 2) {
+    static_for<0, 2>([&](auto R) {
       if (it0 + decltype(R)::value <= geo.NB + 2) body(R, it0 + decltype(R)::value);
     });
   }
@@ -1032,8 +1038,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, float4 *__restrict_
   __syncthreads();
 }
 
-// Wavefront roles: 0 main A, 1 main B, 2 recompute for A, 3 recompute for B, then NH helpers of A, NH helpers of B.
-// The log-domain pipeline for ONE utterance by the workgroup that flagged it (all eight wavefronts; ctc_hvp.hip for the stages).
+// The log-domain pipeline for ONE utterance by the workgroup that flagged it (all ten wavefronts; ctc_hvp.hip for the stages).
 template <int KIND, int NL>
 __device__ __forceinline__ void redo_log_domain(const Problem &p, const Layout &L, char *ws, const float *__restrict__ vec,
                                                 float *__restrict__ loss, float *__restrict__ out, float *lds_f, int w, int b) {
@@ -1080,22 +1085,32 @@ __global__ __launch_bounds__(64 * NW) void hvp_fused_kernel(Problem p, Layout L,
   if (threadIdx.x == 0) { lds.flag = 0; lds.feasible = 0; lds.mode = mode; }
   if (threadIdx.x < NW) lds.l2s[threadIdx.x] = 0.0;
   __syncthreads();
-  if (w == 0) {
+  // Wavefronts w, w + 4, w + 8 share a SIMD (0 and 1 hold three, 2 and 3 two): the main chains -- the busiest wavefronts -- sit on
+  // the two-wavefront SIMDs with one helper each, the recompute chains with two helpers each.
+  if (w == 2) {
     __builtin_amdgcn_s_setprio(3);
     run_main<KIND, NL, 0>(p, rows_ws, kexp_ws, nslot, loss, flag_ws, lds, geo, b);
-  } else if (w == 1) {
+  } else if (w == 3) {
     __builtin_amdgcn_s_setprio(3);
     run_main<KIND, NL, 1>(p, rows_ws, kexp_ws, nslot, loss, flag_ws, lds, geo, b);
-  } else if (w == 2) {
+  } else if (w == 0) {
     __builtin_amdgcn_s_setprio(2);
     run_recompute<KIND, NL, 0>(p, rows_ws, kexp_ws, nslot, stats_ws, vec, lds, geo, b);
-  } else if (w == 3) {
+  } else if (w == 1) {
     __builtin_amdgcn_s_setprio(2);
     run_recompute<KIND, NL, 1>(p, rows_ws, kexp_ws, nslot, stats_ws, vec, lds, geo, b);
-  } else if (w < 4 + NH) {
-    run_helper<KIND, NL, 0>(p, stats_ws, vec, out, lds, geo, w - 4, b);
+  } else if (w == 4) {
+    run_helper<KIND, NL, 0, 0, 2, 0, 2>(p, stats_ws, vec, out, lds, geo, 0, b);
+  } else if (w == 5) {
+    run_helper<KIND, NL, 1, 0, 2, 0, 2>(p, stats_ws, vec, out, lds, geo, 0, b);
+  } else if (w == 6) {
+    run_helper<KIND, NL, 0, 2, 2, 2, 2>(p, stats_ws, vec, out, lds, geo, 1, b);
+  } else if (w == 7) {
+    run_helper<KIND, NL, 1, 2, 2, 2, 2>(p, stats_ws, vec, out, lds, geo, 1, b);
+  } else if (w == 8) {
+    run_helper<KIND, NL, 0, 4, 1, 4, 2>(p, stats_ws, vec, out, lds, geo, 2, b);
   } else {
-    run_helper<KIND, NL, 1>(p, stats_ws, vec, out, lds, geo, w - 4 - NH, b);
+    run_helper<KIND, NL, 1, 4, 1, 4, 2>(p, stats_ws, vec, out, lds, geo, 2, b);
   }
   // utterances the linear domain cannot hold (normally none): redone right here in the log domain, every output row rewritten
   __syncthreads();
