@@ -22,7 +22,11 @@ for n in names:
 dev = torch.device("cuda:0")
 host, d = bench.make_inputs(B, T, U, V, 2, False, dev)
 nbytes = ctypes.c_size_t()
-assert libs[0].ctc_amd_workspace_bytes(_lib.WS_LOSS_GRAD, kind, B, T, V, U, ctypes.byref(nbytes)) == 0
+need = 0
+for lib in libs:  # (diagnostic builds carry extra workspace regions: the largest request serves all)
+    assert lib.ctc_amd_workspace_bytes(_lib.WS_LOSS_GRAD, kind, B, T, V, U, ctypes.byref(nbytes)) == 0
+    need = max(need, nbytes.value)
+nbytes = ctypes.c_size_t(need)
 ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
 loss = torch.empty(B, device=dev); grad = torch.empty(B, T, V, device=dev)
 stream = torch.cuda.current_stream().cuda_stream

@@ -34,6 +34,8 @@
 #undef CTC_F6_Y
 #undef CTC_F6_PFD
 #undef CTC_F6_RN12
+#undef CTC_F6_PRIO1
+#undef CTC_F6_HPRIO_B
 #endif
 
 namespace ctc {

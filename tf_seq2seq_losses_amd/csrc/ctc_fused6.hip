@@ -85,7 +85,7 @@ __device__ Stamps *g_stamps_dummy;
 #define F6_ST_ARG , st_
 #define F6_STAMP_DECL Stamps st_; st_.t0 = __builtin_amdgcn_s_memtime();
 #define F6_STAMP_PHASE2 st_.ph = 1;
-#define F6_BARRIER() do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_.work[st_.ph] += t_ - st_.t0; block_barrier_raw(); \
+#define F6_BARRIER() do { __builtin_amdgcn_s_waitcnt(0xC07F); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_.work[st_.ph] += t_ - st_.t0; block_barrier_raw(); \
     unsigned long long u_ = __builtin_amdgcn_s_memtime(); st_.wait[st_.ph] += u_ - t_; st_.t0 = u_; } while (0)
 #define F6_STAMP_DUMP(wave) do { if ((threadIdx.x & 63) == 0) { unsigned long long *q_ = reinterpret_cast<unsigned long long *>(flag_ws_dbg + p.B) + ((long)b * 16 + (wave)) * 4; \
     q_[0] = st_.work[0]; q_[1] = st_.wait[0]; q_[2] = st_.work[1]; q_[3] = st_.wait[1]; } } while (0)
@@ -476,6 +476,7 @@ struct Rows {
   int tokoff[NL];                       // byte offset of label[i] in the LDS copy of the row (pad slot beyond label_length)
   float mb[4 * VPL];                    // 1.0 at this lane's element that is the blank column
   bool valid[NL];                       // slot i < label_length
+  int scat[NL];                         // byte offset (from bins) of the slot's posterior bin; slots beyond label_length: a word of their own
   float *xs, *bins;
   int lane, blank;
   float dl;
@@ -502,6 +503,16 @@ struct Rows {
     }
 #pragma unroll
     for (int e = 0; e < 4 * VPL; ++e) mb[e] = (256 * (e / 4) + lane * 4 + (e & 3) == p.blank) ? 1.f : 0.f;
+  }
+
+  // LDS rows of this wavefront.  The posterior scatter is branch-free: a slot beyond label_length adds into word `lane` of the
+  // gather copy, which is dead between two E-stage frames (every frame rewrites it before reading) -- a common pad slot would
+  // serialise the adds of a ragged batch, an `if` costs two exec-mask branches per frame.
+  __device__ __forceinline__ void set_lds(float *xs_, float *bins_) {
+    xs = xs_; bins = bins_;
+    const int own = (int)(reinterpret_cast<char *>(xs_) - reinterpret_cast<char *>(bins_)) + 4 * lane;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) scat[j] = valid[j] ? tokoff[j] : own;
   }
 
   // exp(x - rowmax) of this lane's elements from the recorded statistic mxl = rowmax * log2(e)
@@ -571,25 +582,35 @@ struct Rows {
     for (int f = 0; f < Q; ++f) gather(ev[f], e[f]);  // LDS operations of a wavefront execute in program order: one copy serves all
   }
 
-  // gradient row of frame t from the S row of the main chain: sq[0] = blank posterior of this lane, sq[1 + j] = token
-  // posterior of slot j, both in units of 2^-30; ev = exp(x - rowmax) of this lane's elements, inv = 1 / sum exp
-  __device__ __forceinline__ void grad_row(int t, float qb, const float (&qt)[NL], const float4 (&ev)[VPL], float inv) const {
+  // gradient row of frame t from the S row of the main chain: qb = blank posterior of the row, qt[j] = token posterior of slot j,
+  // both in units of 2^-30; ev = exp(x - rowmax) of this lane's elements, inv = 1 / sum exp.  Two halves: the LDS half (bins
+  // cleared, posteriors added, bins read back -- LDS operations of a wavefront execute in order, so the halves of several frames
+  // can be issued back to back through the ONE bin row and their round trips overlap) and the arithmetic + store half.
+  __device__ __forceinline__ void scatter(const float (&qt)[NL], uint4 (&pu)[VPL]) const {
 #pragma unroll
     for (int q = 0; q < VPL; ++q) *reinterpret_cast<uint4 *>(bins + 256 * q + lane * 4) = make_uint4(0u, 0u, 0u, 0u);  // (same type as the atomics and the read: float stores may be reordered against them)
     char *bb = reinterpret_cast<char *>(bins);
 #pragma unroll
-    for (int j = 0; j < NL; ++j)  // (positions beyond label_length sit out: their adds would all hit the one pad slot and serialise)
-      if (valid[j]) atomicAdd(reinterpret_cast<unsigned *>(bb + tokoff[j]), (unsigned)(qt[j] + 0.5f));
+    for (int j = 0; j < NL; ++j) atomicAdd(reinterpret_cast<unsigned *>(bb + scat[j]), valid[j] ? (unsigned)(qt[j] + 0.5f) : 0u);
     wave_lds_fence();  // the bins read below were written by other lanes
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) pu[q] = *reinterpret_cast<const uint4 *>(bins + 256 * q + lane * 4);
+    wave_lds_fence();  // (and the next frame's clear stays behind this read)
+  }
+  __device__ __forceinline__ void grad_out(int t, float qb, const uint4 (&pu)[VPL], const float4 (&ev)[VPL], float inv) const {
     const float c1 = -dl * 9.31322574615478515625e-10f;
     const float c2 = dl * inv;
 #pragma unroll
     for (int q = 0; q < VPL; ++q) {
-      const uint4 pu = *reinterpret_cast<const uint4 *>(bins + 256 * q + lane * 4);
-      const float4 pq = make_float4((float)pu.x + mb[4 * q] * qb, (float)pu.y + mb[4 * q + 1] * qb,
-                                    (float)pu.z + mb[4 * q + 2] * qb, (float)pu.w + mb[4 * q + 3] * qb);
+      const float4 pq = make_float4((float)pu[q].x + mb[4 * q] * qb, (float)pu[q].y + mb[4 * q + 1] * qb,
+                                    (float)pu[q].z + mb[4 * q + 2] * qb, (float)pu[q].w + mb[4 * q + 3] * qb);
       io.store_g(t, q, make_float4(pq.x * c1 + c2 * ev[q].x, pq.y * c1 + c2 * ev[q].y, pq.z * c1 + c2 * ev[q].z, pq.w * c1 + c2 * ev[q].w));
     }
+  }
+  __device__ __forceinline__ void grad_row(int t, float qb, const float (&qt)[NL], const float4 (&ev)[VPL], float inv) const {
+    uint4 pu[VPL];
+    scatter(qt, pu);
+    grad_out(t, qb, pu, ev, inv);
   }
 };
 
@@ -603,6 +624,12 @@ struct Rows {
 #endif
 #ifndef CTC_F6_ONLY  // experiment: which roles work in phase 2 (1 main, 2 recompute, 4 helper E stage, 8 helper G stage) and in phase 1 (16 main, 32 E stage); others only keep the barriers
 #define CTC_F6_ONLY 63
+#endif
+#ifndef CTC_F6_PRIO1  // experiment: issue priority of the main chains before the meeting point / of the helpers of side B
+#define CTC_F6_PRIO1 3
+#endif
+#ifndef CTC_F6_HPRIO_B
+#define CTC_F6_HPRIO_B 0
 #endif
 #ifndef CTC_F6_X
 #define CTC_F6_X 2
@@ -911,6 +938,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
   const int lp_int = lds.lp_int;
   const float cf30 = ldexp_f(lds.cf, 30);
   F6_STAMP_PHASE2
+  if (CTC_F6_PRIO1 != 3) __builtin_amdgcn_s_setprio(3);
 
   // ================= phase 2: everything from LDS =================
   {
@@ -1123,7 +1151,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
     using SP = P1Split<BLK, NH, NL>;
     Rows<KIND, NL, VPL, XT> W;
     W.init(p, b, lane, ll, nullptr, nullptr);
-    W.xs = lds.xcopy_r[SIDE];
+    W.set_lds(lds.xcopy_r[SIDE], nullptr);
     if (lane == 0) W.xs[256 * VPL] = 0.f;  // pad slot of the gather copy: emission 0 for label positions beyond label_length
     float2 *stats = stats_ws + (long)b * T;
     float2 *sinkp = sink_ws + (long)b * 256;
@@ -1234,8 +1262,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
   int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
   if (ll > p.U) ll = 0;
   S.init(p, b, lane, ll, d_loss, grad);
-  S.xs = lds.xcopy[DIR * NH + h];
-  S.bins = lds.bins[DIR * NH + h];
+  S.set_lds(lds.xcopy[DIR * NH + h], lds.bins[DIR * NH + h]);
   if (lane == 0) S.xs[V] = 0.f;  // pad slot of the gather copy
   float2 *stats = stats_ws + (long)b * T;
   float2 *sinkp = sink_ws + (long)b * 256;
@@ -1332,19 +1359,20 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         // first and have the whole iteration (not the part after this block's E stage) to arrive
         static_for<0, FPH>([&](auto Q) { S.io.load_x(X[rn][decltype(Q)::value], fr(2, j + 1, h + NH * decltype(Q)::value)); });
         if (FAST || __builtin_expect(nv == BLK, 1)) {
+          // (three passes over the frames: the gathers of all of them go through the one LDS copy back to back -- in order --
+          // and their round trips overlap instead of adding up)
+          Emis<NL> e[FPH];
           static_for<0, FPH>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
-            const int d = h + NH * q;
             float4 ev[VPL];
-            S.expo(X[r][q], readlane_f(st_cur.x, d), ev);
+            S.expo(X[r][q], readlane_f(st_cur.x, h + NH * q), ev);
             static_for<0, VPL>([&](auto W) {
               constexpr int w = decltype(W)::value;
               X[r][q][w] = make_float4(ev[w].x, ev[w].y, ev[w].z, ev[w].w);
             });
-            Emis<NL> e;
-            S.gather(ev, e);
-            write_E(E[d], e);
           });
+          static_for<0, FPH>([&](auto Q) { S.gather(X[r][decltype(Q)::value], e[decltype(Q)::value]); });
+          static_for<0, FPH>([&](auto Q) { write_E(E[h + NH * decltype(Q)::value], e[decltype(Q)::value]); });
         } else {
           for (int d = h; d < nv; d += NH) {
             float4 xr[VPL], ev[VPL];
@@ -1411,11 +1439,16 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
           static_assert(FPH == 3, "one four-value reduction");
           const float qall = swap_reduce<FPH + 1, false>(qb);  // blank posteriors of the FPH frames and one total mass
           massbad |= !(fabsf(readlane_f(qall, SwapLanes<4>::lane(FPH)) - 1073741824.0f) < 1073741824.0f * 1e-4f);
+          constexpr bool BATCH = !RELOAD && VPL == 1;  // (register budget: FPH more row sets)
+          uint4 PU[BATCH ? FPH : 1][VPL];
+          if constexpr (BATCH) static_for<0, FPH>([&](auto Q) { S.scatter(qt[decltype(Q)::value], PU[decltype(Q)::value]); });
           static_for<0, FPH>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             const int d = h + NH * q;
             const float qbs = readlane_f(qall, SwapLanes<4>::lane(q));
-            if constexpr (RELOAD) {
+            if constexpr (BATCH) {
+              S.grad_out(geo.frame(DIR, g, d), qbs, PU[q], X[rg][q], readlane_f(SG[rg].y, d));
+            } else if constexpr (RELOAD) {
               float4 ev[VPL];
               S.expo(XG[q], readlane_f(sgl.x, d), ev);
               S.grad_row(geo.frame(DIR, g, d), qbs, qt[q], ev, readlane_f(sgl.y, d));
@@ -1503,10 +1536,10 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused6_kernel(Problem p, La
   if (threadIdx.x < Lds<KIND, NL, NH, BLK, VPL>::NW) lds.l2s[threadIdx.x] = 0.0;
   __syncthreads();
   if (w == 0) {
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(CTC_F6_PRIO1);
     run_main<KIND, NL, NH, BLK, VPL, 0>(p, L, alpha_ws, beta_ws, kexp_ws, logp_ws, loss, flag_ws, meet_ws, lds, geo, grad != nullptr, b);
   } else if (w == 1) {
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(CTC_F6_PRIO1);
     run_main<KIND, NL, NH, BLK, VPL, 1>(p, L, alpha_ws, beta_ws, kexp_ws, logp_ws, loss, flag_ws, meet_ws, lds, geo, grad != nullptr, b);
   } else if (w == 2) {
     __builtin_amdgcn_s_setprio(2);
@@ -1517,6 +1550,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused6_kernel(Problem p, La
   } else if (w < 4 + NH) {
     run_helper<KIND, NL, NH, BLK, VPL, 0, XT>(p, L, stats_ws, sink_ws, d_loss, grad, lds, geo, w - 4, b, flag_ws);
   } else {
+    if (CTC_F6_HPRIO_B != 0) __builtin_amdgcn_s_setprio(CTC_F6_HPRIO_B);
     run_helper<KIND, NL, NH, BLK, VPL, 1, XT>(p, L, stats_ws, sink_ws, d_loss, grad, lds, geo, w - 4 - NH, b, flag_ws);
   }
   // Utterances the linear domain cannot hold (flags D1..D6, normally none): the same wavefronts redo them in the log
