@@ -117,9 +117,11 @@ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 template <int BLK, int NL>
 struct Cad {
 #ifndef CTC_F6_RN12
-#define CTC_F6_RN12 4
+#define CTC_F6_RN12 6
 #endif
-  static constexpr int RN = (BLK % 4 == 0) ? CTC_F6_RN12 : 3;
+  // 12-frame blocks: two label positions per lane renormalise every 6 frames (r03: with the posterior scale in two factors the
+  // longer period no longer raises D5 on long utterances; -4 us at the north-star shape), one position per lane every 4
+  static constexpr int RN = (BLK % 4 == 0) ? (NL == 2 ? CTC_F6_RN12 : 4) : 3;
   static constexpr int NG = BLK / RN;            // exponent groups of the rows of one block
   static constexpr int LV = (RN + NL - 1) / NL;  // adoption levels: lanes the lattice front can cross in one period
   static_assert(BLK % RN == 0, "block length must be a multiple of the renormalisation period");
@@ -549,16 +551,21 @@ struct Rows {
 #pragma unroll
       for (int q = 1; q < VPL; ++q) m[f] = vmax3_raw(vmax3_raw(m[f], xr[f][q].x, xr[f][q].y), xr[f][q].z, xr[f][q].w);
     }
-    constexpr bool SWAP = (Q == 2 || Q == 4);  // (ctc_swap_reduce.h: all Q values through one register)
+    constexpr bool SWAP = (Q >= 2 && Q <= 4);  // (ctc_swap_reduce.h: all Q values through one register; three ride as four)
+    constexpr int QP = SWAP ? (Q == 3 ? 4 : Q) : 2;
     float mall = 0.f;
-    if constexpr (SWAP) mall = swap_reduce<Q, true>(m);
-    else dpp_max_n<Q>(m);
+    if constexpr (SWAP) {
+      float mp[QP];
+#pragma unroll
+      for (int f = 0; f < QP; ++f) mp[f] = m[f < Q ? f : Q - 1];
+      mall = swap_reduce<QP, true>(mp);
+    } else dpp_max_n<Q>(m);
     float4 ev[Q][VPL];
     float part[Q];
 #pragma unroll
     for (int f = 0; f < Q; ++f) {
       float mx;
-      if constexpr (SWAP) mx = readlane_f(mall, SwapLanes<SWAP ? Q : 2>::lane(f));
+      if constexpr (SWAP) mx = readlane_f(mall, SwapLanes<QP>::lane(f));
       else mx = readlane_f(m[f], 63);
       mx = (mx == -INFINITY) ? 0.f : mx;
       mxl[f] = mx * LOG2E;
@@ -568,12 +575,16 @@ struct Rows {
       for (int q = 1; q < VPL; ++q) part[f] += (ev[f][q].x + ev[f][q].y) + (ev[f][q].z + ev[f][q].w);
     }
     float sall = 0.f;
-    if constexpr (SWAP) sall = swap_reduce<Q, false>(part);
-    else dpp_sum_n<Q>(part);
+    if constexpr (SWAP) {
+      float pp[QP];
+#pragma unroll
+      for (int f = 0; f < QP; ++f) pp[f] = f < Q ? part[f] : 0.f;
+      sall = swap_reduce<QP, false>(pp);
+    } else dpp_sum_n<Q>(part);
     float prod = 1.f;
 #pragma unroll
     for (int f = 0; f < Q; ++f) {
-      if constexpr (SWAP) sm[f] = readlane_f(sall, SwapLanes<SWAP ? Q : 2>::lane(f));
+      if constexpr (SWAP) sm[f] = readlane_f(sall, SwapLanes<QP>::lane(f));
       else sm[f] = readlane_f(part[f], 63);
       prod = (f == 0) ? sm[0] : prod * sm[f];
     }
@@ -602,9 +613,12 @@ struct Rows {
     const float c2 = dl * inv;
 #pragma unroll
     for (int q = 0; q < VPL; ++q) {
-      const float4 pq = make_float4((float)pu[q].x + mb[4 * q] * qb, (float)pu[q].y + mb[4 * q + 1] * qb,
-                                    (float)pu[q].z + mb[4 * q + 2] * qb, (float)pu[q].w + mb[4 * q + 3] * qb);
-      io.store_g(t, q, make_float4(pq.x * c1 + c2 * ev[q].x, pq.y * c1 + c2 * ev[q].y, pq.z * c1 + c2 * ev[q].z, pq.w * c1 + c2 * ev[q].w));
+      // (explicit fused multiply-adds: every instantiation -- storage format, batched or per-frame G stage -- rounds alike, which
+      // the format tests check bit for bit)
+      const float4 pq = make_float4(__builtin_fmaf(mb[4 * q], qb, (float)pu[q].x), __builtin_fmaf(mb[4 * q + 1], qb, (float)pu[q].y),
+                                    __builtin_fmaf(mb[4 * q + 2], qb, (float)pu[q].z), __builtin_fmaf(mb[4 * q + 3], qb, (float)pu[q].w));
+      const float4 sv = make_float4(c2 * ev[q].x, c2 * ev[q].y, c2 * ev[q].z, c2 * ev[q].w);
+      io.store_g(t, q, make_float4(__builtin_fmaf(pq.x, c1, sv.x), __builtin_fmaf(pq.y, c1, sv.y), __builtin_fmaf(pq.z, c1, sv.z), __builtin_fmaf(pq.w, c1, sv.w)));
     }
   }
   __device__ __forceinline__ void grad_row(int t, float qb, const float (&qt)[NL], const float4 (&ev)[VPL], float inv) const {
