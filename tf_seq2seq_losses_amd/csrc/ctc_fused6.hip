@@ -124,8 +124,25 @@ struct Cad {
   static constexpr int RN = (BLK % 4 == 0) ? (NL == 2 ? CTC_F6_RN12 : 4) : 3;
   static constexpr int NG = BLK / RN;            // exponent groups of the rows of one block
   static constexpr int LV = (RN + NL - 1) / NL;  // adoption levels: lanes the lattice front can cross in one period
+  static constexpr int NSEG = 2 * NG + 1;        // posterior-scale segments of one block (kl_segment)
   static_assert(BLK % RN == 0, "block length must be a multiple of the renormalisation period");
 };
+
+// The per-lane posterior scale of the main chain's S rows (run_main) changes when the R rows enter a new exponent group -- before
+// the products of that group's first frame -- and after every renormalisation of the main chain; it is written once per such
+// SEGMENT, not once per frame (an LDS write per frame on the one wavefront whose instruction count bounds phase 2).  This is the
+// segment of position d of a block with nv frames; the main chain counts its own, the helpers look theirs up.
+template <int KIND, int DIR, int RN>
+__device__ __forceinline__ constexpr int kl_segment(int d, int nv) {
+  int seg = -1, q = -1;
+  for (int dd = 0; dd <= d; ++dd) {
+    const int s = (KIND == 0 && DIR == 1) ? nv - dd : nv - 1 - dd;
+    const int qd = (s > 0 ? s - 1 : 0) / RN;
+    if (qd != q) { q = qd; ++seg; }
+    if (dd < d && (dd + 1) % RN == 0) ++seg;
+  }
+  return seg;
+}
 
 template <int KIND, int NL, int NH, int BLK, int VPL>
 struct Lds {
@@ -139,7 +156,7 @@ struct Lds {
   float E[2][3][BLK][ES];   // [side][block % 3]
   float R[2][3][BLK][RS];   // [side][block % 3]
   int kg[2][3][NG][64];     // per-lane exponents of the R rows, one set per renormalisation group
-  float kl[2][3][BLK][64];  // per-lane posterior scale of the S rows' raw parts (written by the main chain with every S row)
+  float kl[2][3][Cad<BLK, NL>::NSEG][64];  // per-lane posterior scale of the S rows' raw parts, one per segment (kl_segment)
   float xcopy[2 * NH][V + 4];
   float xcopy_r[2][V + 4];  // row copies of the recompute waves (E stage of phase 1)
   float bins[2 * NH][V + 4];
@@ -551,8 +568,8 @@ struct Rows {
 #pragma unroll
       for (int q = 1; q < VPL; ++q) m[f] = vmax3_raw(vmax3_raw(m[f], xr[f][q].x, xr[f][q].y), xr[f][q].z, xr[f][q].w);
     }
-    constexpr bool SWAP = (Q >= 2 && Q <= 4);  // (ctc_swap_reduce.h: all Q values through one register; three ride as four)
-    constexpr int QP = SWAP ? (Q == 3 ? 4 : Q) : 2;
+    constexpr bool SWAP = (Q >= 1 && Q <= 4);  // (ctc_swap_reduce.h: all Q values through one register; one rides as two, three as four)
+    constexpr int QP = SWAP ? (Q == 3 ? 4 : Q == 1 ? 2 : Q) : 2;
     float mall = 0.f;
     if constexpr (SWAP) {
       float mp[QP];
@@ -951,6 +968,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
   }
   const int lp_int = lds.lp_int;
   const float cf30 = ldexp_f(lds.cf, 30);
+  const bool carrier = lane == (DIR == 0 ? 0 : 63);
   F6_STAMP_PHASE2
   if (CTC_F6_PRIO1 != 3) __builtin_amdgcn_s_setprio(3);
 
@@ -979,20 +997,23 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
         // S row entry per lane (in place of the R row, a region of 2 NL floats):
         //   NL >= 2: [aligned blank part (raw), token parts[NL] (raw; simplified: the shifted slot scaled), shifted blank part (scaled)]
         //   NL = 1 : [token part, shifted blank part]
-        // lane 0's shifted blank part also carries the posterior of the boundary state (scaled with its own K0).
+        // the carrier lane's shifted blank part also holds the posterior of the boundary state (scaled with its own K0).
         float(*KLr)[64] = lds.kl[DIR][j % 3];
-        int q = -1, kR = DEAD, ks = DEAD, k0r = DEAD;
+        int q = -1, kR = DEAD, ks = DEAD, seg = -1;
         float KL = 0.f, KS = 0.f, K0 = 0.f;
         float PL = 1.f, PS = 1.f, P0 = 1.f;  // pre-scale of the chain's operand for the aligned / shifted / boundary products
         bool wide = false;                   // wave-uniform: some lane's scale exceeds 2^KK_MAX in this exponent group
         auto setK = [&]() __attribute__((always_inline)) {
-          const int ka = S.k + kR - lp_int, kb = S.k + ks - lp_int, kc = S.kx + k0r - lp_int;
+          // (the boundary state's posterior rides in the shifted part of the CARRIER lane -- 0 for A, 63 for B, the lane that holds
+          // the R row's state next to the boundary -- so it needs no cross-lane read; K0 is zero on every other lane)
+          const int ka = S.k + kR - lp_int, kb = S.k + ks - lp_int, kc = carrier ? S.kx + kR - lp_int : DEAD;
           const int kmx = imax(ka, imax(kb, kc));
           // D5 proper: only beyond 2^KK_MAX2 (see KK_MAX)
           kflag |= (kmx > KK_MAX2);
           KL = ldexp_f(cf30, imin(ka, KK_MAX));
           KS = ldexp_f(cf30, imin(kb, KK_MAX));
-          K0 = ldexp_f(cf30, imin(kc, KK_MAX));
+          K0 = carrier ? ldexp_f(cf30, imin(kc, KK_MAX)) : 0.f;
+          KLr[++seg][lane] = KL;
           wide = __builtin_amdgcn_ballot_w64(kmx > KK_MAX) != 0;
           if (wide) {
             PL = ldexp_f(1.f, imin(imax(ka - KK_MAX, 0), KK_MAX2 - KK_MAX));
@@ -1004,13 +1025,12 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
           if (qd != q) {  // new exponent group of the rows (the boundary exponent r.kx is constant inside a group as well)
             q = qd; kR = kRq;
             ks = (DIR == 0) ? from_next_lane_i(kR, r.kx) : from_prev_lane_i(kR, r.kx);
-            k0r = readlane_i(kR, DIR == 0 ? 0 : 63);
             setK();
           }
           // the value one label position over: from the next lane for A (needs l = i+1 of a row that holds l = i), from the
           // previous lane for B; and the row's state at this chain's boundary position (l = 0 for A, l = UP for B)
           const float rs = (DIR == 0) ? from_next_lane(r.c[0], r.cx) : from_prev_lane(r.c[NL - 1], r.cx);
-          const float r0 = (DIR == 0) ? readlane_f(r.c[0], 0) : readlane_f(r.c[NL - 1], 63);
+          const float r0 = (DIR == 0) ? r.c[0] : r.c[NL - 1];  // (meaningful on the carrier lane only)
           float qal = 0.f, tok[NL], qsh, p0;
           if constexpr (KIND == 0) {
             if constexpr (DIR == 0) S.step(e);  // A: posterior of frame t from alpha[t+1], beta[t+1]
@@ -1080,7 +1100,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
             };
             if (__builtin_expect(!wide, 1)) parts(std::false_type{}); else parts(std::true_type{});
           }
-          qsh = (lane == 0) ? qsh + p0 * K0 : qsh;  // the boundary state (uniform) rides in lane 0's scaled part
+          qsh = __builtin_fmaf(p0, K0, qsh);  // the boundary state rides in the carrier lane's scaled part
           float *srow = RR[d] + 2 * lane * NL;
           if constexpr (NL == 1) *reinterpret_cast<float2 *>(srow) = make_float2(tok[0], qsh);
           else if constexpr (NL == 2) *reinterpret_cast<float4 *>(srow) = make_float4(qal, tok[0], tok[1], qsh);
@@ -1094,7 +1114,6 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
               *reinterpret_cast<float4 *>(srow + 4 * q4) = make_float4(sv[4 * q4], sv[4 * q4 + 1], sv[4 * q4 + 2], sv[4 * q4 + 3]);
             *reinterpret_cast<float2 *>(srow + NL) = make_float2(sv[NL], sv[NL + 1]);
           }
-          KLr[d][lane] = KL;
           if constexpr (!(KIND == 0 && DIR == 0)) S.step(e);
           if (ren) { S.template renorm<LV>(); setK(); }
         };
@@ -1327,12 +1346,21 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
   // ================= phase 2: E stage (statistics from the record), G stage three blocks behind =================
   {
     const int nb = geo.nblocks(2, DIR);
+    int segq[FPH];  // posterior-scale segment of this helper's positions in a full block
+#pragma unroll
+    for (int q = 0; q < FPH; ++q) segq[q] = kl_segment<KIND, DIR, Cad<BLK, NL>::RN>(h + NH * q, BLK);
     if (h == 0 && DIR == 0) S.io.zero_rows(len, T);  // padded frames (base_loss.py:291-296)
     // Rows of a block are loaded one block ahead of its E stage, exponentiated there (in place) and used again by its G
     // stage three blocks later: a ring of five register sets addressed by (block mod 5) at COMPILE time.  Wide vocabularies
     // (four row segments per lane) hold two sets; their G stage re-reads and re-exponentiates its rows.
     constexpr bool RELOAD = VPL >= 4;
-    constexpr int RING = RELOAD ? 2 : 5;
+    // LA: blocks of look-ahead of the row loads (and of the per-frame statistics).  Two blocks (a six-set ring) were measured in r03:
+    // 193 against 149 us at B = 256, 137 against 128 at B = 64 -- one block it stays.
+#ifndef CTC_F6_LA
+#define CTC_F6_LA 1
+#endif
+    constexpr int LA = (RELOAD || VPL > 1) ? 1 : CTC_F6_LA;
+    constexpr int RING = RELOAD ? 2 : 4 + LA;
     float4 X[RING][FPH][VPL];
     float4 XG[RELOAD ? FPH : 1][VPL];
     float2 SG[RING];
@@ -1343,11 +1371,14 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         static_for<0, VPL>([&](auto W) { X[decltype(R)::value][decltype(Q)::value][decltype(W)::value] = make_float4(0.f, 0.f, 0.f, 0.f); });
       });
     });
-    float2 st_cur = make_float2(0.f, 0.f), st_next = make_float2(0.f, 0.f);
+    float2 st_cur = make_float2(0.f, 0.f), st_n1 = make_float2(0.f, 0.f), st_next = make_float2(0.f, 0.f);
     bool massbad = false;
     if (nb > 0) {
-      static_for<0, FPH>([&](auto Q) { S.io.load_x(X[0][decltype(Q)::value], fr(2, 0, h + NH * decltype(Q)::value)); });
+      static_for<0, LA>([&](auto A) {
+        static_for<0, FPH>([&](auto Q) { S.io.load_x(X[decltype(A)::value][decltype(Q)::value], fr(2, decltype(A)::value, h + NH * decltype(Q)::value)); });
+      });
       st_cur = stats[fr(2, 0, lane)];
+      if constexpr (LA == 2) st_n1 = stats[fr(2, 1, lane)];
     }
     // FAST: steady state (E stage on a full block, G stage on a full block): no branch around a memory operation, so the
     // `s_waitcnt vmcnt(N)` hipcc derives for the ring leave the look-ahead loads AND the gradient stores of the last
@@ -1355,8 +1386,8 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
     auto body = [&](auto R, auto FASTt, int it) __attribute__((always_inline)) {
       constexpr bool FAST = decltype(FASTt)::value;
       constexpr int r = decltype(R)::value;         // = it mod RING
-      constexpr int rn = (r + 1) % RING;            // block it+1 (being loaded)
-      constexpr int rg = (r + 2) % RING;            // block it-3 (G stage; five-set ring only)
+      constexpr int rn = (r + LA) % RING;           // block it+LA (being loaded)
+      constexpr int rg = (r + LA + 1) % RING;       // block it-3 (G stage; not with RELOAD)
       if constexpr (RELOAD) {
         static_for<0, FPH>([&](auto Q) { S.io.load_x(XG[decltype(Q)::value], fr(2, it - 3, h + NH * decltype(Q)::value)); });
         sgl = stats[fr(2, it - 3, lane)];
@@ -1368,10 +1399,10 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         const int g = geo.absblock(2, DIR, j);
         const int nv = FAST ? BLK : geo.nvof(g);
         float(*E)[LD::ES] = lds.E[DIR][j % 3];
-        st_next = stats[fr(2, j + 1, lane)];
+        st_next = stats[fr(2, j + LA, lane)];
         // rows of the next block: their register set was freed by the G stage of the previous iteration, so the loads go out
         // first and have the whole iteration (not the part after this block's E stage) to arrive
-        static_for<0, FPH>([&](auto Q) { S.io.load_x(X[rn][decltype(Q)::value], fr(2, j + 1, h + NH * decltype(Q)::value)); });
+        static_for<0, FPH>([&](auto Q) { S.io.load_x(X[rn][decltype(Q)::value], fr(2, j + LA, h + NH * decltype(Q)::value)); });
         if (FAST || __builtin_expect(nv == BLK, 1)) {
           // (three passes over the frames: the gathers of all of them go through the one LDS copy back to back -- in order --
           // and their round trips overlap instead of adding up)
@@ -1398,7 +1429,8 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
             write_E(E[d], e);
           }
         }
-        st_cur = st_next;
+        if constexpr (LA == 2) { st_cur = st_n1; st_n1 = st_next; }
+        else st_cur = st_next;
       }
       // ---- G stage (block it-3): posterior scatter + gradient rows ----
       const int gj = it - 3;
@@ -1406,11 +1438,11 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         const int g = geo.absblock(2, DIR, gj);
         const int nv = FAST ? BLK : geo.nvof(g);
         const float(*SR)[LD::RS] = lds.R[DIR][gj % 3];
-        const float(*KLr)[64] = lds.kl[DIR][gj % 3];
+        const float(*KLr)[64] = lds.kl[DIR][gj % 3];  // [segment][lane]
         // S row entry -> blank posterior of the lane and token posteriors of its slots, all in units of 2^-30 (see run_main)
-        auto read_S = [&](int d, float &qb, float (&qt)[NL]) __attribute__((always_inline)) {
+        auto read_S = [&](int d, int sg, float &qb, float (&qt)[NL]) __attribute__((always_inline)) {
           const float *srow = SR[d] + 2 * lane * NL;
-          const float kl = KLr[d][lane];
+          const float kl = KLr[sg][lane];
           constexpr int JS = (KIND == 1) ? (DIR == 0 ? NL - 1 : 0) : -1;  // simplified: the slot whose token part is already scaled
           float qal = 0.f, qsh;
           if constexpr (NL == 1) { const float2 t = *reinterpret_cast<const float2 *>(srow); qt[0] = t.x; qsh = t.y; }
@@ -1439,7 +1471,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
           float qb[FPH + 1], qt[FPH][NL];
           static_for<0, FPH>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
-            read_S(h + NH * q, qb[q], qt[q]);
+            read_S(h + NH * q, segq[q], qb[q], qt[q]);
           });
           qb[FPH] = qb[0];
 #pragma unroll
@@ -1477,7 +1509,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
             const float2 sd = stats[geo.frame(DIR, g, d)];
             S.expo(xr, sd.x, ev);
             float qb, qt[NL];
-            read_S(d, qb, qt);
+            read_S(d, kl_segment<KIND, DIR, Cad<BLK, NL>::RN>(d, nv), qb, qt);
             float tot = qb;
 #pragma unroll
             for (int jj = 0; jj < NL; ++jj) tot += qt[jj];
