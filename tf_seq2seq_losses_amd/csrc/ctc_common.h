@@ -35,6 +35,7 @@
 #undef CTC_F6_PFD
 #undef CTC_F6_RN12
 #undef CTC_F6_PRIO1
+#undef CTC_F6_NH12
 #undef CTC_F6_LA
 #undef CTC_F6_HPRIO_B
 #endif

@@ -784,6 +784,18 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
 
 // Everything the workgroup does for utterance b (the body of fused5_kernel; also called by fused6_kernel for the utterances
 // the linear-domain recursion cannot hold, on the same wavefront roles, LDS reused).
+// a wavefront without a role (the caller runs more wavefronts than 4 + 2 NH): the barriers of the roles, nothing else
+template <int BLK>
+__device__ __forceinline__ void run_idle(const Problem &p, bool want_grad, int b) {
+  Geo<BLK> geo;
+  geo.init(clampi(p.logit_length[b], 0, p.T));
+  for (int it = 0; it <= geo.NB; ++it) block_barrier();
+  __syncthreads();
+  __syncthreads();
+  if (!want_grad) return;
+  for (int it = 0; it <= geo.NB + 2; ++it) block_barrier();
+}
+
 template <int KIND, int NL, int NH, int BLK, int VPL, int XT>
 __device__ __forceinline__ void run_roles(const Problem &p, const Layout &L, float *__restrict__ alpha_ws, float *__restrict__ beta_ws,
                                           double *__restrict__ logp_ws, float2 *__restrict__ stats_ws, float *__restrict__ loss,

@@ -130,16 +130,22 @@ struct Cad {
 
 // The per-lane posterior scale of the main chain's S rows (run_main) changes when the R rows enter a new exponent group -- before
 // the products of that group's first frame -- and after every renormalisation of the main chain; it is written once per such
-// SEGMENT, not once per frame (an LDS write per frame on the one wavefront whose instruction count bounds phase 2).  This is the
-// segment of position d of a block with nv frames; the main chain counts its own, the helpers look theirs up.
+// SEGMENT, not once per frame (an LDS write per frame on the one wavefront whose instruction count bounds phase 2).  The main
+// chain of phase 2 renormalises ren_shift() frames early (after positions RN-2, 2 RN-2, ... where the R rows change group at
+// RN-1, 2 RN-1, ...), so that both events open ONE segment and the scales are rebuilt once per period.  kl_segment: the segment
+// of position d of a block with nv frames; the main chain counts its own, the helpers look theirs up.
+template <int KIND, int DIR>
+__device__ __forceinline__ constexpr int ren_shift() { return (KIND == 0 && DIR == 1) ? 0 : 1; }
 template <int KIND, int DIR, int RN>
 __device__ __forceinline__ constexpr int kl_segment(int d, int nv) {
   int seg = -1, q = -1;
   for (int dd = 0; dd <= d; ++dd) {
     const int s = (KIND == 0 && DIR == 1) ? nv - dd : nv - 1 - dd;
     const int qd = (s > 0 ? s - 1 : 0) / RN;
-    if (qd != q) { q = qd; ++seg; }
-    if (dd < d && (dd + 1) % RN == 0) ++seg;
+    bool open = qd != q;
+    q = qd;
+    if (dd > 0 && (dd + ren_shift<KIND, DIR>()) % RN == 0) open = true;  // the main chain renormalised after position dd - 1
+    if (open) ++seg;
   }
   return seg;
 }
@@ -656,6 +662,9 @@ struct Rows {
 #ifndef CTC_F6_ONLY  // experiment: which roles work in phase 2 (1 main, 2 recompute, 4 helper E stage, 8 helper G stage) and in phase 1 (16 main, 32 E stage); others only keep the barriers
 #define CTC_F6_ONLY 63
 #endif
+#ifndef CTC_F6_NH12   // helpers per side of the 12-frame-block instantiations (V <= 256, U <= 128).  6 = sixteen wavefronts, two frames per
+#define CTC_F6_NH12 4 // helper and block, was built and measured in r03: 134 against 127 us at B = 64, 161 against 151 at B = 256 (same box) --
+#endif                // the main chains lose more to two extra wavefronts on their SIMDs than the helpers gain.  Diagnostic builds only.
 #ifndef CTC_F6_PRIO1  // experiment: issue priority of the main chains before the meeting point / of the helpers of side B
 #define CTC_F6_PRIO1 3
 #endif
@@ -670,12 +679,14 @@ struct Rows {
 #endif
 template <int BLK, int NH, int NL>
 struct P1Split {
-  // (NH = 1, the 3-frame blocks of the 8-positions-per-lane variant: two frames for the helper, one for the recompute wavefront)
-  static constexpr int X = NH == 4 ? CTC_F6_X : NH == 2 ? BLK / 3 : 2, Y = NH == 4 ? CTC_F6_Y : NH == 2 ? BLK / 3 : 0;
-  static constexpr int R = NH == 4 ? BLK - 2 * X - 2 * Y : NH == 2 ? BLK - X - Y : BLK - X;
-  static_assert(NH == 4 || NH == 2 || NH == 1, "helpers per side");
+  // (NH = 1, the 3-frame blocks of the 8-positions-per-lane variant: two frames for the helper, one for the recompute wavefront;
+  // NH = 6, sixteen wavefronts: two frames for every helper, none for the recompute wavefronts)
+  static constexpr int X = NH == 6 ? BLK / 6 : NH == 4 ? CTC_F6_X : NH == 2 ? BLK / 3 : 2, Y = NH == 6 ? BLK / 6 : NH == 4 ? CTC_F6_Y : NH == 2 ? BLK / 3 : 0;
+  static constexpr int R = NH == 6 ? 0 : NH == 4 ? BLK - 2 * X - 2 * Y : NH == 2 ? BLK - X - Y : BLK - X;
+  static_assert(NH == 6 || NH == 4 || NH == 2 || NH == 1, "helpers per side");
   static_assert(X >= 0 && Y >= 0 && R >= 0 && X <= 6 && Y <= 6 && R <= 6, "phase-1 split: at most 6 frames per worker");
   static constexpr int count(int worker) {
+    if (NH == 6) return worker < 6 ? X : R;
     if (NH == 4) return worker < 2 ? X : worker < 4 ? Y : R;
     if (NH == 1) return worker == 0 ? X : R;
     return worker == 0 ? X : worker == 1 ? Y : R;
@@ -1003,6 +1014,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
         float KL = 0.f, KS = 0.f, K0 = 0.f;
         float PL = 1.f, PS = 1.f, P0 = 1.f;  // pre-scale of the chain's operand for the aligned / shifted / boundary products
         bool wide = false;                   // wave-uniform: some lane's scale exceeds 2^KK_MAX in this exponent group
+        bool dirty = false;                  // the scales have to be rebuilt before the next products
         auto setK = [&]() __attribute__((always_inline)) {
           // (the boundary state's posterior rides in the shifted part of the CARRIER lane -- 0 for A, 63 for B, the lane that holds
           // the R row's state next to the boundary -- so it needs no cross-lane read; K0 is zero on every other lane)
@@ -1025,8 +1037,9 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
           if (qd != q) {  // new exponent group of the rows (the boundary exponent r.kx is constant inside a group as well)
             q = qd; kR = kRq;
             ks = (DIR == 0) ? from_next_lane_i(kR, r.kx) : from_prev_lane_i(kR, r.kx);
-            setK();
+            dirty = true;
           }
+          if (dirty) { setK(); dirty = false; }  // (also: this chain renormalised after the previous frame)
           // the value one label position over: from the next lane for A (needs l = i+1 of a row that holds l = i), from the
           // previous lane for B; and the row's state at this chain's boundary position (l = 0 for A, l = UP for B)
           const float rs = (DIR == 0) ? from_next_lane(r.c[0], r.cx) : from_prev_lane(r.c[NL - 1], r.cx);
@@ -1115,7 +1128,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
             *reinterpret_cast<float2 *>(srow + NL) = make_float2(sv[NL], sv[NL + 1]);
           }
           if constexpr (!(KIND == 0 && DIR == 0)) S.step(e);
-          if (ren) { S.template renorm<LV>(); setK(); }
+          if (ren) { S.template renorm<LV>(); dirty = true; }
         };
         if (nv == BLK) {
           // emission rows of the whole block and the exponent groups up front, R rows PR frames ahead of their use
@@ -1131,7 +1144,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
             if constexpr (d + PR < BLK) read_R<KIND, NL, LD>(RR[d + PR], lane, rb[d + PR]);
             constexpr int s = (KIND == 0 && DIR == 1) ? BLK - d : BLK - 1 - d;
             constexpr int qd = (s > 0 ? s - 1 : 0) / RN;
-            one(d, qd, (d + 1) % RN == 0, eb[d], rb[d], kq[qd]);
+            one(d, qd, (d + 1 + ren_shift<KIND, DIR>()) % RN == 0, eb[d], rb[d], kq[qd]);
           });
         } else {
           for (int d = 0; d < nv; ++d) {
@@ -1140,7 +1153,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
             RRow<KIND, NL> r;
             read_R<KIND, NL, LD>(RR[d], lane, r);
             const int qd = grp(d);
-            one(d, qd, (d + 1) % RN == 0 || d == nv - 1, e, r, KG[qd][lane]);
+            one(d, qd, (d + 1 + ren_shift<KIND, DIR>()) % RN == 0 || d == nv - 1, e, r, KG[qd][lane]);
           }
         }
       }
@@ -1323,7 +1336,16 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
   // ================= phase 1: E stage with statistics =================
   if (!p.resume) {
     using SP = P1Split<BLK, NH, NL>;
-    if constexpr (NH == 4) {
+    if constexpr (NH == 6) {
+      switch (h) {
+        case 0: estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, sinkp, dump, lane, wave F6_ST_ARG); break;
+        case 1: estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(1), SP::count(1)>(S, lds, geo, stats, sinkp, dump, lane, wave F6_ST_ARG); break;
+        case 2: estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(2), SP::count(2)>(S, lds, geo, stats, sinkp, dump, lane, wave F6_ST_ARG); break;
+        case 3: estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(3), SP::count(3)>(S, lds, geo, stats, sinkp, dump, lane, wave F6_ST_ARG); break;
+        case 4: estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(4), SP::count(4)>(S, lds, geo, stats, sinkp, dump, lane, wave F6_ST_ARG); break;
+        default: estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(5), SP::count(5)>(S, lds, geo, stats, sinkp, dump, lane, wave F6_ST_ARG); break;
+      }
+    } else if constexpr (NH == 4) {
       switch (h) {
         case 0: estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(0), SP::count(0)>(S, lds, geo, stats, sinkp, dump, lane, wave F6_ST_ARG); break;
         case 1: estage1<KIND, NL, NH, BLK, VPL, XT, DIR, SP::first(1), SP::count(1)>(S, lds, geo, stats, sinkp, dump, lane, wave F6_ST_ARG); break;
@@ -1468,7 +1490,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
           // qb[FPH]: total posterior mass of this helper's first frame of the block (D6).  Mass lost by a chain is missing
           // from every frame between the place of the loss and the end of that chain's range, so one frame per helper
           // and block (4 spread over the 12) sees it.
-          float qb[FPH + 1], qt[FPH][NL];
+          float qb[4], qt[FPH][NL];
           static_for<0, FPH>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             read_S(h + NH * q, segq[q], qb[q], qt[q]);
@@ -1476,14 +1498,16 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
           qb[FPH] = qb[0];
 #pragma unroll
           for (int jj = 0; jj < NL; ++jj) qb[FPH] += qt[0][jj];
+#pragma unroll
+          for (int f = FPH + 1; f < 4; ++f) qb[f] = 0.f;
 #ifdef CTC_F6_DEBUG2
           if (DIR == 0 && gj == 0 && h == 1 && NL == 2) {  // what helper 1 of side A reads for position d = 1 of the first block
             int *dbg = flag_ws_dbg + p.B + (long)b * 2048 + 1024;
             dbg[lane] = __float_as_int(qb[0]); dbg[64 + lane] = __float_as_int(qt[0][0]); dbg[128 + lane] = __float_as_int(qt[0][NL - 1]);
           }
 #endif
-          static_assert(FPH == 3, "one four-value reduction");
-          const float qall = swap_reduce<FPH + 1, false>(qb);  // blank posteriors of the FPH frames and one total mass
+          static_assert(FPH == 3 || FPH == 2, "one four-value reduction");
+          const float qall = swap_reduce<4, false>(qb);  // blank posteriors of the FPH frames and one total mass
           massbad |= !(fabsf(readlane_f(qall, SwapLanes<4>::lane(FPH)) - 1073741824.0f) < 1073741824.0f * 1e-4f);
           constexpr bool BATCH = !RELOAD && VPL == 1;  // (register budget: FPH more row sets)
           uint4 PU[BATCH ? FPH : 1][VPL];
@@ -1564,8 +1588,9 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused6_kernel(Problem p, La
   // (the log-domain roles reuse the LDS once the linear-domain ones are done with it)
   __shared__ __attribute__((aligned(16))) union LdsBoth {
     Lds<KIND, NL, NH, BLK, VPL> lin;
-    fused5::Lds<KIND, NL, NH, BLK, VPL> log;
+    fused5::Lds<KIND, NL, (NH == 6 ? 4 : NH), BLK, VPL> log;  // (the log-domain roles know up to four helpers per side)
   } both;
+  constexpr int NH5 = NH == 6 ? 4 : NH;
   Lds<KIND, NL, NH, BLK, VPL> &lds = both.lin;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = perm ? perm[blockIdx.x] : (int)blockIdx.x;
@@ -1609,7 +1634,8 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused6_kernel(Problem p, La
   __syncthreads();
   if (fl != 0) {
     __builtin_amdgcn_s_setprio(0);
-    fused5::run_roles<KIND, NL, NH, BLK, VPL, XT>(p, L, alpha_ws, beta_ws, logp_ws, stats_ws, loss, d_loss, grad, sink_ws, both.log, w, b);
+    if (w < 4 + 2 * NH5) fused5::run_roles<KIND, NL, NH5, BLK, VPL, XT>(p, L, alpha_ws, beta_ws, logp_ws, stats_ws, loss, d_loss, grad, sink_ws, both.log, w, b);
+    else fused5::run_idle<BLK>(p, grad != nullptr, b);  // wavefronts the log-domain roles have no work for keep their barriers
   }
   // sum(loss) for the training loop, without a launch of its own (ctc_amd_loss_grad_sum): the thread that wrote loss[b] --
   // lane 0 of main chain A in either domain -- adds it in fixed point; the second call of a loss / gradient pair adds nothing
@@ -1683,7 +1709,7 @@ hipError_t CTC_F6_ENTRY(const Problem &p, const Layout &L, char *ws, float *loss
   return p.V <= 256 ? launch6<4, 2, 6, 1>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st)
                     : launch6<4, 2, 6, 2>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st);
 #else
-  return p.V <= 256   ? launch6<CTC_FUSED6_NL, 4, 12, 1>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st)
+  return p.V <= 256   ? launch6<CTC_FUSED6_NL, CTC_F6_NH12, 12, 1>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st)
          : p.V <= 512 ? launch6<CTC_FUSED6_NL, 2, 6, 2>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st)
                       : launch6<CTC_FUSED6_NL, 2, 6, 4>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st);
 #endif
