@@ -1376,13 +1376,15 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
     // stage three blocks later: a ring of five register sets addressed by (block mod 5) at COMPILE time.  Wide vocabularies
     // (four row segments per lane) hold two sets; their G stage re-reads and re-exponentiates its rows.
     constexpr bool RELOAD = VPL >= 4;
-    // LA: blocks of look-ahead of the row loads (and of the per-frame statistics).  Two blocks (a six-set ring) were measured in r03:
-    // 193 against 149 us at B = 256, 137 against 128 at B = 64 -- one block it stays.
+    // LA = 1: rows of block it+1 requested at the top of iteration it.  LA = 2: the register set the G stage has just consumed
+    // (block it-3) takes the rows of block it+2 at once, at the END of iteration it -- nearly two blocks of look-ahead with the same
+    // five sets.  Measured in r03 (one process, same box): LA = 2 153 us against 139 at B = 256, 131 against 125 at B = 64; a six-set
+    // ring spills (193 against 149).  More look-ahead does not help this kernel; LA = 2 stays a diagnostic switch.
 #ifndef CTC_F6_LA
 #define CTC_F6_LA 1
 #endif
-    constexpr int LA = (RELOAD || VPL > 1) ? 1 : CTC_F6_LA;
-    constexpr int RING = RELOAD ? 2 : 4 + LA;
+    constexpr int LA = RELOAD ? 1 : CTC_F6_LA;
+    constexpr int RING = RELOAD ? 2 : 5;
     float4 X[RING][FPH][VPL];
     float4 XG[RELOAD ? FPH : 1][VPL];
     float2 SG[RING];
@@ -1408,8 +1410,8 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
     auto body = [&](auto R, auto FASTt, int it) __attribute__((always_inline)) {
       constexpr bool FAST = decltype(FASTt)::value;
       constexpr int r = decltype(R)::value;         // = it mod RING
-      constexpr int rn = (r + LA) % RING;           // block it+LA (being loaded)
-      constexpr int rg = (r + LA + 1) % RING;       // block it-3 (G stage; not with RELOAD)
+      constexpr int rn = (r + 1) % RING;            // block it+1 (LA = 1: being loaded)
+      constexpr int rg = (r + 2) % RING;            // block it-3 (G stage; not with RELOAD), then block it+2 (LA = 2)
       if constexpr (RELOAD) {
         static_for<0, FPH>([&](auto Q) { S.io.load_x(XG[decltype(Q)::value], fr(2, it - 3, h + NH * decltype(Q)::value)); });
         sgl = stats[fr(2, it - 3, lane)];
@@ -1421,10 +1423,12 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
         const int g = geo.absblock(2, DIR, j);
         const int nv = FAST ? BLK : geo.nvof(g);
         float(*E)[LD::ES] = lds.E[DIR][j % 3];
-        st_next = stats[fr(2, j + LA, lane)];
-        // rows of the next block: their register set was freed by the G stage of the previous iteration, so the loads go out
-        // first and have the whole iteration (not the part after this block's E stage) to arrive
-        static_for<0, FPH>([&](auto Q) { S.io.load_x(X[rn][decltype(Q)::value], fr(2, j + LA, h + NH * decltype(Q)::value)); });
+        if constexpr (LA == 1) {
+          st_next = stats[fr(2, j + 1, lane)];
+          // rows of the next block: their register set was freed by the G stage of the previous iteration, so the loads go out
+          // first and have the whole iteration (not the part after this block's E stage) to arrive
+          static_for<0, FPH>([&](auto Q) { S.io.load_x(X[rn][decltype(Q)::value], fr(2, j + 1, h + NH * decltype(Q)::value)); });
+        }
         if (FAST || __builtin_expect(nv == BLK, 1)) {
           // (three passes over the frames: the gathers of all of them go through the one LDS copy back to back -- in order --
           // and their round trips overlap instead of adding up)
@@ -1451,8 +1455,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
             write_E(E[d], e);
           }
         }
-        if constexpr (LA == 2) { st_cur = st_n1; st_n1 = st_next; }
-        else st_cur = st_next;
+        if constexpr (LA == 1) st_cur = st_next;
       }
       // ---- G stage (block it-3): posterior scatter + gradient rows ----
       const int gj = it - 3;
@@ -1542,6 +1545,11 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
             S.grad_row(geo.frame(DIR, g, d), qb, qt, ev, sd.y);
           }
         }
+      }
+      if constexpr (LA == 2) {  // (unconditional, clamped frame indices: no branch around a memory operation)
+        st_next = stats[fr(2, it + 2, lane)];
+        static_for<0, FPH>([&](auto Q) { S.io.load_x(X[rg][decltype(Q)::value], fr(2, it + 2, h + NH * decltype(Q)::value)); });
+        st_cur = st_n1; st_n1 = st_next;
       }
       F6_BARRIER();
     };
