@@ -83,6 +83,50 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Accessors of workspace rows.  COH = false: plain loads / stores (producer and consumer are different launches).  COH = true: rows
+// handed from one workgroup to another INSIDE a launch (ctc_wide.hip): the eight XCDs of the chip have one L2 each, which are not
+// coherent with one another during a kernel, so such rows are written through and read past them -- relaxed agent-scope atomics
+// compile to global_store / global_load with sc1 set (32 / 64 bits each; wider accesses are split).  Ordering is the caller's:
+// a producer waits for its stores (s_waitcnt vmcnt(0)) before it raises a flag, a consumer issues its loads after it has seen the flag.
+// (The formally obvious alternative -- plain accesses with agent-scope release / acquire fences -- writes back / invalidates a whole
+// L2 per fence: measured 4x slower than the three-kernel pipeline with one fence per row.)
+template <bool COH> __device__ __forceinline__ float ld1(const float *p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH> __device__ __forceinline__ float2 ld2(const float *p) {
+  if constexpr (COH) {
+    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+  } else {
+    return *reinterpret_cast<const float2 *>(p);
+  }
+}
+template <bool COH> __device__ __forceinline__ float4 ld4(const float *p) {
+  if constexpr (COH) {
+    const float2 a = ld2<true>(p), b = ld2<true>(p + 2);
+    return make_float4(a.x, a.y, b.x, b.y);
+  } else {
+    return *reinterpret_cast<const float4 *>(p);
+  }
+}
+template <bool COH> __device__ __forceinline__ void st1(float *p, float v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool COH> __device__ __forceinline__ void st2(float *p, float2 v) {
+  if constexpr (COH) {
+    const unsigned long long u = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *reinterpret_cast<float2 *>(p) = v;
+  }
+}
+template <bool COH> __device__ __forceinline__ void st4(float *p, float4 v) {
+  if constexpr (COH) { st2<true>(p, make_float2(v.x, v.y)); st2<true>(p + 2, make_float2(v.z, v.w)); }
+  else *reinterpret_cast<float4 *>(p) = v;
+}
+
 // ---- wave64 reductions with DPP (result broadcast through an SGPR) ----
 // Hand-written: hipcc lowers __builtin_amdgcn_update_dpp reductions to mov + mov_dpp + op per level (18 instructions
 // per reduction); here every level is ONE DPP-fused VALU op.  Lanes without a valid DPP source are disabled and keep

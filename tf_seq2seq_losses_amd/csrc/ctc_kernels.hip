@@ -15,6 +15,7 @@
 #include "ctc_amd.h"
 #include "ctc_swap_reduce.h"
 #include "ctc_v1_device.h"
+#include "ctc_grad_row.h"
 
 namespace ctc {
 
@@ -171,39 +172,54 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
   const int32_t *lab = p.labels + (long)b * p.label_stride;
   const float *ra = alpha + ((long)b * (p.T + 1) + (KIND == 0 ? t + 1 : t)) * L.SRS;
   const float *rb = beta + ((long)b * (p.T + 1) + t + 1) * L.SRS;
-  const int offpos = (KIND == 0 ? 2 * UP : UP) + 2;
-  // alpha~ + beta~ + (offsets - log P) is summed in double: with logits ~1e10 the three addends are each ~1e10 and
-  // cancel to O(1) (README.md:74-78 promises sane outputs there); float addition would lose the result entirely.
-  const double scale = (double)ra[offpos] + (double)ra[offpos + 1] + (double)rb[offpos] + (double)rb[offpos + 1] - lp;
-  auto post = [&](float a_, float b_) -> float { return fminf(fexp2((float)((double)a_ + (double)b_ + scale)), 1.0f); };  // a posterior never exceeds 1
-  auto post3 = [&](float a_, float b_, float c_) -> float { return fminf(fexp2((float)((double)a_ + (double)b_ + (double)c_ + scale)), 1.0f); };
-  float qblank = 0.f;
-  if constexpr (KIND == 0) {
-    for (int i = lane; i < UP; i += 64) {
-      float2 a = *reinterpret_cast<const float2 *>(ra + 2 * i);
-      float2 bb = *reinterpret_cast<const float2 *>(rb + 2 * i);
-      qblank += post(a.x, bb.x);
-      if (i < ll) {
-        float q = post(a.y, bb.y);
-        int tok = (i < p.label_stride) ? lab[i] : p.blank;
-        if (tok >= 0 && tok < V && tok != p.blank) atomicAdd(&ubin[tok], tofix(q));
-      }
+  // Posteriors normalised by the frame's OWN mass sum_s alpha_t[s] beta_t[s] (= P for every t: the invariant of the reference's
+  // tests/test_classic_ctc_loss.py:146-167; see ctc_grad_row.h): the row offsets cancel, so the sums stay in float32 even with
+  // logits ~1e10 (README.md:74-78), and the rounding of a long sweep does not enter as a common factor.  Three passes over the
+  // two lattice rows (L1 hits): maximum, sum, scatter.
+  const float *er = emis + row * (long)L.ERS;
+  const float bl = (KIND == 1) ? er[UP] : 0.f;
+  // log2 (alpha beta) of the blank state and of the token state of label position i (NEG when there is none)
+  auto terms = [&](int i, float &tb, float &tt) {
+    if constexpr (KIND == 0) {
+      const float2 a = *reinterpret_cast<const float2 *>(ra + 2 * i);
+      const float2 bb = *reinterpret_cast<const float2 *>(rb + 2 * i);
+      tb = a.x + bb.x;
+      tt = (i < ll) ? a.y + bb.y : NEG;
+    } else {
+      const float ai = ra[i], bi = rb[i];  // state l = i+1 in both rows
+      tb = ai + bi + bl;
+      tt = (i < ll) ? ((i == 0) ? ra[UP] : ra[i - 1]) + er[i] + bi : NEG;  // a[t, l=i] * y[t,i] * b[t+1, l=i+1]
     }
-    if (lane == 0) qblank += post(ra[2 * UP], rb[2 * UP]);
-  } else {
-    const float *er = emis + row * (long)L.ERS;
-    const float bl = er[UP];
-    for (int i = lane; i < UP; i += 64) {
-      float ai = ra[i], bi = rb[i];  // state l = i+1 in both rows
-      qblank += post3(ai, bi, bl);
-      if (i < ll) {
-        float aprev = (i == 0) ? ra[UP] : ra[i - 1];  // a[t, l = i]
-        float q = post3(aprev, er[i], bi);  // a[t, l=i] * y[t,i] * b[t+1, l=i+1]
-        int tok = (i < p.label_stride) ? lab[i] : p.blank;
-        if (tok >= 0 && tok < V && tok != p.blank) atomicAdd(&ubin[tok], tofix(q));
-      }
+  };
+  const float t0 = (KIND == 0) ? ra[2 * UP] + rb[2 * UP] : ra[UP] + rb[UP] + bl;  // the l = 0 state
+  float m = t0;
+  for (int i = lane; i < UP; i += 64) {
+    float tb, tt;
+    terms(i, tb, tt);
+    m = fmaxf(m, fmaxf(tb, tt));
+  }
+  m = wave_max(m);
+  if (!(m > NEG_THR)) {  // no alignment passes through this frame (cannot happen on a feasible sample)
+    if (gvec) for (int k = lane * 4; k < V; k += 256) gput4(k, make_float4(0.f, 0.f, 0.f, 0.f));
+    else for (int k = lane; k < V; k += 64) gput(k, 0.f);
+    return;
+  }
+  float ssum = (lane == 0) ? fexp2(t0 - m) : 0.f;
+  for (int i = lane; i < UP; i += 64) {
+    float tb, tt;
+    terms(i, tb, tt);
+    ssum += fexp2(tb - m) + fexp2(tt - m);  // (NEG - m underflows to 0)
+  }
+  const float inv = 1.0f / wave_sum(ssum);  // the sum is >= 1: the maximum contributes 2^0
+  float qblank = (lane == 0) ? fexp2(t0 - m) * inv : 0.f;
+  for (int i = lane; i < UP; i += 64) {
+    float tb, tt;
+    terms(i, tb, tt);
+    qblank += fexp2(tb - m) * inv;
+    if (i < ll) {
+      const int tok = (i < p.label_stride) ? lab[i] : p.blank;
+      if (tok >= 0 && tok < V && tok != p.blank) atomicAdd(&ubin[tok], tofix(fexp2(tt - m) * inv));
     }
-    if (lane == 0) qblank += post3(ra[UP], rb[UP], bl);
   }
   qblank = wave_sum(qblank);
   if (lane == 0 && p.blank >= 0 && p.blank < V) ubin[p.blank] = tofix(qblank);
@@ -369,114 +385,21 @@ hipError_t run_log_posterior(const Problem &p, const Layout &L, char *ws, float 
   return hipGetLastError();
 }
 
-// Wide vocabularies (V > 1024, float32 rows, 16-byte aligned): the same gradient with the vocabulary walked in passes of
-// 1024 columns.  The posterior of every label position is computed ONCE into a per-wavefront table (fixed point); each
-// pass zeroes a 4 KB bin array, adds the positions whose token falls into it, and streams its 1024 columns (logits in,
-// gradient out).  LDS per wavefront is 8 KB whatever V is (grad_kernel needs 4 V bytes: at V = 8192 that left 4
-// wavefronts per CU and 2.3 TB/s), and the bins are touched twice per column instead of four times.
-template <int KIND>
+// Wide vocabularies (V > 1024, float32 rows, 16-byte aligned): one wavefront per frame, the vocabulary walked in passes of 1024
+// columns, posteriors normalised by the frame's own mass (ctc_grad_row.h).  LDS per wavefront is 4 KB of bins + 256 NL bytes
+// whatever V is (grad_kernel needs 4 V bytes: at V = 8192 that left 4 wavefronts per CU and 2.3 TB/s).
+template <int KIND, int NL>
 __global__ __launch_bounds__(256) void grad_wide_kernel(Problem p, Layout L, const float *__restrict__ emis,
                                                          const float *__restrict__ alpha, const float *__restrict__ beta,
-                                                         const double *__restrict__ logp, const float *__restrict__ d_loss,
-                                                         float *__restrict__ grad) {
-  constexpr int CH = 1024;
-  __shared__ __attribute__((aligned(16))) unsigned bins_s[4][CH];
-  __shared__ unsigned qtab_s[4][CTC_AMD_MAX_U];
+                                                         const float *__restrict__ d_loss, float *__restrict__ grad) {
+  __shared__ __attribute__((aligned(16))) unsigned bins_s[4][1024];
+  __shared__ unsigned qtab_s[4][64 * NL];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long row = (long)blockIdx.x * 4 + w;
   if (row >= (long)p.B * p.T) return;
-  const int b = (int)(row / p.T), t = (int)(row % p.T);
-  const int V = p.V, UP = L.UP;
-  float *g = grad + (long)b * p.gsb + (long)t * p.gst;
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  auto gput4 = [&](int k, float4 r) {
-    v4f v = {r.x, r.y, r.z, r.w};
-    __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(g + k));
-  };
-  const int len = clampi(p.logit_length[b], 0, p.T);
-  const double lp = logp[b];
-  if (t >= len || lp == -INFINITY) {  // padded frames and infeasible samples: exactly zero (base_loss.py:283-298)
-    for (int k = lane * 4; k < V; k += 256) gput4(k, make_float4(0.f, 0.f, 0.f, 0.f));
-    return;
-  }
-  const int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
-  unsigned *bins = bins_s[w];
-  unsigned *qtab = qtab_s[w];
-  auto tofix = [](float q) -> unsigned { return (unsigned)(fminf(q, 1.0f) * 1073741824.0f + 0.5f); };
-  const int32_t *lab = p.labels + (long)b * p.label_stride;
-  const float *ra = alpha + ((long)b * (p.T + 1) + (KIND == 0 ? t + 1 : t)) * L.SRS;
-  const float *rb = beta + ((long)b * (p.T + 1) + t + 1) * L.SRS;
-  const int offpos = (KIND == 0 ? 2 * UP : UP) + 2;
-  const double scale = (double)ra[offpos] + (double)ra[offpos + 1] + (double)rb[offpos] + (double)rb[offpos + 1] - lp;
-  auto post = [&](float a_, float b_) -> float { return fminf(fexp2((float)((double)a_ + (double)b_ + scale)), 1.0f); };
-  auto post3 = [&](float a_, float b_, float c_) -> float { return fminf(fexp2((float)((double)a_ + (double)b_ + (double)c_ + scale)), 1.0f); };
-  // posteriors of the label positions (see grad_kernel for the regrouping), once per row
-  float qblank = 0.f;
-  if constexpr (KIND == 0) {
-    for (int i = lane; i < UP; i += 64) {
-      const float2 a = *reinterpret_cast<const float2 *>(ra + 2 * i);
-      const float2 bb = *reinterpret_cast<const float2 *>(rb + 2 * i);
-      qblank += post(a.x, bb.x);
-      qtab[i] = (i < ll) ? tofix(post(a.y, bb.y)) : 0u;
-    }
-    if (lane == 0) qblank += post(ra[2 * UP], rb[2 * UP]);
-  } else {
-    const float *er = emis + row * (long)L.ERS;
-    const float bl = er[UP];
-    for (int i = lane; i < UP; i += 64) {
-      const float ai = ra[i], bi = rb[i];
-      qblank += post3(ai, bi, bl);
-      const float aprev = (i == 0) ? ra[UP] : ra[i - 1];
-      qtab[i] = (i < ll) ? tofix(post3(aprev, er[i], bi)) : 0u;
-    }
-    if (lane == 0) qblank += post3(ra[UP], rb[UP], bl);
-  }
-  const unsigned qbfix = tofix(wave_sum(qblank));
-  const float dl = d_loss ? d_loss[b] : 1.0f;
-  const float *x = p.logits + (long)b * p.xsb + (long)t * p.xst;
-  const float mx = emis[row * (long)L.ERS + UP + 1];
-  const float l2s = emis[row * (long)L.ERS + UP + 2];
-  const bool wrt_logits = p.wrt == 0;
-  for (int c0 = 0; c0 < V; c0 += CH) {
-    float4 xv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {  // this pass's logits first: four loads in flight under the LDS work
-      const int k = c0 + lane * 4 + 256 * q;
-      xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (wrt_logits && k < V) xv[q] = *reinterpret_cast<const float4 *>(x + k);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4 *>(bins + lane * 4 + 256 * q) = make_uint4(0u, 0u, 0u, 0u);
-    wave_lds_fence();  // (LDS operations of one wavefront execute in program order)
-    for (int i = lane; i < ll; i += 64) {
-      const int tok = (i < p.label_stride) ? lab[i] : p.blank;
-      const unsigned r = (unsigned)(tok - c0);
-      if (tok >= 0 && tok < V && tok != p.blank && r < (unsigned)CH) atomicAdd(&bins[r], qtab[i]);
-    }
-    if (lane == 0 && p.blank >= c0 && p.blank < c0 + CH && p.blank < V) bins[p.blank - c0] = qbfix;
-    wave_lds_fence();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int k = c0 + lane * 4 + 256 * q;
-      if (k < V) {
-        const uint4 u = *reinterpret_cast<const uint4 *>(bins + lane * 4 + 256 * q);
-        const float c = 9.31322574615478515625e-10f;
-        float4 r;
-        if (wrt_logits) {
-          // g_x[k] = d_loss * (softmax(x)[k] - post[k])  (TF autodiff of tools.py:37-39 applied to base_loss.py:150-153)
-          r.x = dl * (fexp2((xv[q].x - mx) * LOG2E - l2s) - (float)u.x * c);
-          r.y = dl * (fexp2((xv[q].y - mx) * LOG2E - l2s) - (float)u.y * c);
-          r.z = dl * (fexp2((xv[q].z - mx) * LOG2E - l2s) - (float)u.z * c);
-          r.w = dl * (fexp2((xv[q].w - mx) * LOG2E - l2s) - (float)u.w * c);
-        } else {
-          r = make_float4(-dl * ((float)u.x * c), -dl * ((float)u.y * c), -dl * ((float)u.z * c), -dl * ((float)u.w * c));  // base_loss.py:262-268
-        }
-        gput4(k, r);
-      }
-    }
-    wave_lds_fence();
-  }
+  grad_row<KIND, NL, false>(p, L, emis, alpha, beta, d_loss, grad, (int)(row / p.T), (int)(row % p.T), lane, bins_s[w], qtab_s[w],
+                            [](int) {});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -591,8 +514,12 @@ hipError_t run_grad(const Problem &p, const Layout &L, char *ws, const float *d_
                     ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0 && L.UP <= CTC_AMD_MAX_U;
   if (wide) {
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    if (p.kind == 0) hipLaunchKernelGGL(grad_wide_kernel<0>, grid, block, 0, st, p, L, emis, alpha, beta, logp, d_loss, grad);
-    else hipLaunchKernelGGL(grad_wide_kernel<1>, grid, block, 0, st, p, L, emis, alpha, beta, logp, d_loss, grad);
+#define CTC_GW(K, N) hipLaunchKernelGGL((grad_wide_kernel<K, N>), grid, block, 0, st, p, L, emis, alpha, beta, d_loss, grad)
+#define CTC_GW_NL(K) switch (L.NL) { case 1: CTC_GW(K, 1); break; case 2: CTC_GW(K, 2); break; case 4: CTC_GW(K, 4); break; \
+                                     case 8: CTC_GW(K, 8); break; case 16: CTC_GW(K, 16); break; default: return hipErrorInvalidValue; }
+    if (p.kind == 0) { CTC_GW_NL(0) } else { CTC_GW_NL(1) }
+#undef CTC_GW_NL
+#undef CTC_GW
     return hipGetLastError();
   }
   int wpb = 4;

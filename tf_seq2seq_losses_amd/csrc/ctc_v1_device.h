@@ -5,12 +5,15 @@
 // See ctc_kernels.hip for the algorithms and the reference lines.
 #pragma once
 #include "ctc_common.h"
+#include "ctc_amd.h"
 
 namespace ctc {
 
 __device__ __forceinline__ int v1_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-// one frame (b, t) by one wavefront
+// one frame (b, t) by one wavefront (COH: the row is read by other workgroups of the same launch, ctc_common.h; MAXI: label
+// positions per lane the caller can meet)
+template <bool COH = false, int MAXI = CTC_AMD_MAX_U / 64>
 __device__ __forceinline__ void emit_row(const Problem &p, const Layout &L, float *__restrict__ emis, int b, int t, int lane) {
   const long row = (long)b * p.T + t;
   const int len = v1_clampi(p.logit_length[b], 0, p.T);
@@ -23,6 +26,18 @@ __device__ __forceinline__ void emit_row(const Problem &p, const Layout &L, floa
   const unsigned short *xh = reinterpret_cast<const unsigned short *>(p.logits) + xoff;  // valid for bfloat16 only
   const bool bf = p.xdtype != 0;
   auto xat = [&](int k) -> float { return bf ? bf16_to_f32(xh[k]) : x[k]; };
+
+  // the label tokens are requested FIRST, beside the row itself: fetched after the statistics they made the gathers below two
+  // dependent round trips (label -> token -> logit) with nothing else of the wavefront in flight.  (The gathers themselves stay
+  // behind the row pass, where they hit in L2: issued up front they were 64 scattered misses each.)
+  int tokv[MAXI];
+#pragma unroll
+  for (int n = 0; n < MAXI; ++n) {
+    const int i = lane + 64 * n;
+    tokv[n] = -1;
+    if (i < L.UP && i < ll) tokv[n] = (i < p.label_stride) ? p.labels[(long)b * p.label_stride + i] : p.blank;
+  }
+  const bool blank_ok = p.blank >= 0 && p.blank < V;
 
   float mx = -INFINITY, sum = 0.f, log2sum = 0.f;
   if (p.wrt == 0) {
@@ -68,26 +83,23 @@ __device__ __forceinline__ void emit_row(const Problem &p, const Layout &L, floa
   }
   // log2 p(token k) = (x[k] - mx) * log2e - log2sum  (one rounding chain, no cancellation for huge logits)
   float *erow = emis + row * (long)L.ERS;
-  for (int i = lane; i < L.UP; i += 64) {
-    float e = NEG;
-    if (i < ll) {
-      int tok = (i < p.label_stride) ? p.labels[(long)b * p.label_stride + i] : p.blank;
+#pragma unroll
+  for (int n = 0; n < MAXI; ++n) {
+    const int i = lane + 64 * n;
+    if (i < L.UP) {
       // (a label equal to the blank id is unsupported input in the reference; every tier treats it as an impossible
       // emission: the sample comes out infeasible, loss +inf, gradient 0)
-      if (tok >= 0 && tok < V && tok != p.blank) e = fmaxf((xat(tok) - mx) * LOG2E - log2sum, NEG);
+      const bool ok = tokv[n] >= 0 && tokv[n] < V && tokv[n] != p.blank;
+      float e = ok ? fmaxf((xat(ok ? tokv[n] : 0) - mx) * LOG2E - log2sum, NEG) : NEG;
       if (!(e == e)) e = NEG;
+      st1<COH>(erow + i, e);
     }
-    erow[i] = e;
   }
   if (lane == 0) {
-    float bl = NEG;
-    if (p.blank >= 0 && p.blank < V) bl = fmaxf((xat(p.blank) - mx) * LOG2E - log2sum, NEG);
+    float bl = blank_ok ? fmaxf((xat(p.blank) - mx) * LOG2E - log2sum, NEG) : NEG;
     if (!(bl == bl)) bl = NEG;
-    erow[L.UP] = bl;
     // softmax(x)[k] = exp2((x[k] - mx) * log2e - log2sum); kept as two terms so that huge logits cancel exactly
-    erow[L.UP + 1] = mx;
-    erow[L.UP + 2] = log2sum;
-    erow[L.UP + 3] = 0.f;
+    st4<COH>(erow + L.UP, make_float4(bl, mx, log2sum, 0.f));
   }
 }
 
@@ -98,24 +110,24 @@ struct ERow {
   float bl;
 };
 
-template <int NL>
+template <int NL, bool COH = false>
 __device__ __forceinline__ void load_erow(ERow<NL> &r, const float *__restrict__ base, int lane, int UP, int vz) {
   const float *p = base + lane * NL;
   if constexpr (NL == 1) {
-    r.y[0] = p[0];
+    r.y[0] = ld1<COH>(p);
   } else if constexpr (NL == 2) {
-    float2 v = *reinterpret_cast<const float2 *>(p);
+    float2 v = ld2<COH>(p);
     r.y[0] = v.x; r.y[1] = v.y;
   } else {
 #pragma unroll
     for (int q = 0; q < NL / 4; ++q) {
-      float4 v = *reinterpret_cast<const float4 *>(p + 4 * q);
+      float4 v = ld4<COH>(p + 4 * q);
       r.y[4 * q] = v.x; r.y[4 * q + 1] = v.y; r.y[4 * q + 2] = v.z; r.y[4 * q + 3] = v.w;
     }
   }
   // the blank emission is wave-uniform; fetched as a VECTOR load (vz = opaque zero): a scalar load returns out of
   // order, so its use forces lgkmcnt(0), i.e. a wait for the youngest prefetch of the ring instead of the oldest
-  r.bl = base[UP + vz];
+  r.bl = ld1<COH>(base + UP + vz);
 }
 
 // store NL consecutive (a, b) pairs of this lane
@@ -243,17 +255,19 @@ struct Scan {
   }
 
   // row layout: see Layout in ctc_common.h.  The 16-byte tail (l = 0 state + offset) is wave-uniform data
-  // written by every lane to the same address, which keeps the store branch-free.
+  // written by every lane to the same address, which keeps the store branch-free (ONE: by lane 0 alone -- rows staged in LDS,
+  // where 64 writes to one address would queue up, ctc_wide.hip).
+  template <bool ONE = false>
   __device__ __forceinline__ void store_row(float *__restrict__ row, int lane, int UP) const {
     const float oh = (float)off;
     const float ol = (float)(off - (double)oh);
     if constexpr (DIR == 0) {
       if constexpr (KIND == 0) {
         store_pairs<NL>(row, lane, c, o);
-        *reinterpret_cast<float4 *>(row + 2 * UP) = make_float4(cx, NEG, oh, ol);
+        if (!ONE || lane == 0) *reinterpret_cast<float4 *>(row + 2 * UP) = make_float4(cx, NEG, oh, ol);
       } else {
         store_singles<NL>(row, lane, c);
-        *reinterpret_cast<float4 *>(row + UP) = make_float4(cx, 0.f, oh, ol);
+        if (!ONE || lane == 0) *reinterpret_cast<float4 *>(row + UP) = make_float4(cx, 0.f, oh, ol);
       }
     } else {
       float cs[NL];  // state of label position l = i+1 lives in the next slot's c
@@ -263,10 +277,10 @@ struct Scan {
       const float c00 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c[0])));  // state l = 0 (lane 0, slot 0)
       if constexpr (KIND == 0) {
         store_pairs<NL>(row, lane, cs, o);
-        *reinterpret_cast<float4 *>(row + 2 * UP) = make_float4(c00, c00, oh, ol);
+        if (!ONE || lane == 0) *reinterpret_cast<float4 *>(row + 2 * UP) = make_float4(c00, c00, oh, ol);
       } else {
         store_singles<NL>(row, lane, cs);
-        *reinterpret_cast<float4 *>(row + UP) = make_float4(c00, 0.f, oh, ol);
+        if (!ONE || lane == 0) *reinterpret_cast<float4 *>(row + UP) = make_float4(c00, 0.f, oh, ol);
       }
     }
   }
