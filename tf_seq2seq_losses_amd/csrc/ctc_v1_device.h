@@ -12,8 +12,8 @@ namespace ctc {
 __device__ __forceinline__ int v1_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // one frame (b, t) by one wavefront (COH: the row is read by other workgroups of the same launch, ctc_common.h; MAXI: label
-// positions per lane the caller can meet)
-template <bool COH = false, int MAXI = CTC_AMD_MAX_U / 64>
+// positions per lane the caller can meet; DEPTH: 16-byte loads per lane in flight while the row is read)
+template <bool COH = false, int MAXI = CTC_AMD_MAX_U / 64, int DEPTH = 8>
 __device__ __forceinline__ void emit_row(const Problem &p, const Layout &L, float *__restrict__ emis, int b, int t, int lane) {
   const long row = (long)b * p.T + t;
   const int len = v1_clampi(p.logit_length[b], 0, p.T);
@@ -46,21 +46,21 @@ __device__ __forceinline__ void emit_row(const Problem &p, const Layout &L, floa
       // exp(x - maximum)) of its own columns, the lanes are combined once at the end (two passes with one load in flight
       // each read a V = 2048 row at 2.7 TB/s chip-wide)
       float m = -INFINITY, s = 0.f;
-      for (int k0 = lane * 4; k0 < V; k0 += 256 * 8) {
-        float4 v[8];
+      for (int k0 = lane * 4; k0 < V; k0 += 256 * DEPTH) {
+        float4 v[DEPTH];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < DEPTH; ++q) {
           const int k = k0 + 256 * q;
           v[q] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
           if (k < V) v[q] = *reinterpret_cast<const float4 *>(x + k);
         }
         float cm = m;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) cm = fmaxf(fmaxf(cm, fmaxf(v[q].x, v[q].y)), fmaxf(v[q].z, v[q].w));
+        for (int q = 0; q < DEPTH; ++q) cm = fmaxf(fmaxf(cm, fmaxf(v[q].x, v[q].y)), fmaxf(v[q].z, v[q].w));
         const float mr = (cm == -INFINITY) ? 0.f : cm;
         s *= fexp2((m - mr) * LOG2E);  // (m = -inf: s is 0 and stays 0)
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < DEPTH; ++q)
           s += (fexp2((v[q].x - mr) * LOG2E) + fexp2((v[q].y - mr) * LOG2E)) + (fexp2((v[q].z - mr) * LOG2E) + fexp2((v[q].w - mr) * LOG2E));
         m = cm;
       }

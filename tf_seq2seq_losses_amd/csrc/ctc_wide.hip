@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void wide_kernel(Problem p, Layout L, float *_
       if (j >= nq) continue;
       const int t = 4 * outside_in(j, nq) + (rid & 3);
       if (t >= len) continue;
-      emit_row<true, NL>(p, L, emis, b, t, lane);
+      emit_row<true, NL, 16>(p, L, emis, b, t, lane);  // (16 KB per wavefront in flight: the pass is latency-bound per wavefront)
       asm volatile("" ::: "memory");
       if (lane == 0 && pend != nullptr) __hip_atomic_fetch_add(pend, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       pend = sv.cnt(b) + t / CHUNK;
