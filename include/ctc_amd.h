@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CTC_AMD_ABI_VERSION 3
+#define CTC_AMD_ABI_VERSION 4
 
 /* lattice variant */
 #define CTC_AMD_CLASSIC 0    /* classic_ctc_loss.py:33-70   (collapse repeats, then drop blanks)   */
@@ -78,6 +78,7 @@ extern "C" {
 /* element types of the producer formats (ctc_amd_loss_grad_ex) */
 #define CTC_AMD_F32 0
 #define CTC_AMD_BF16 1
+#define CTC_AMD_F16 2 /* IEEE half: read / written by the three-kernel pipeline (the fused tiers take float32 and bfloat16) */
 
 /* ABI version of the loaded library (== CTC_AMD_ABI_VERSION of the header it was built from). */
 int ctc_amd_abi_version(void);
@@ -203,8 +204,8 @@ int ctc_amd_hessian(int kind, int wrt,
                     void *workspace, size_t workspace_bytes, void *stream);
 
 /*
- * ctc_amd_loss_grad for the formats a producer kernel hands over: logits (and the gradient written back) as float32 or
- * bfloat16, with arbitrary element strides of the batch and time axes -- time-major [T,B,V] activations are
+ * ctc_amd_loss_grad for the formats a producer kernel hands over: logits (and the gradient written back) as float32,
+ * bfloat16 or float16 (CTC_AMD_F32 / CTC_AMD_BF16 / CTC_AMD_F16), with arbitrary element strides of the batch and time axes -- time-major [T,B,V] activations are
  * logits_stride_b = V, logits_stride_t = B*V; the token axis is contiguous.  Arithmetic is float32 either way.
  * Replaces: the `logit_to_logproba` entry of ctc_loss (base_loss.py:59, tools.py:27-40), which the reference can only
  * feed with a contiguous float32 [B,T,V] tensor (a transposed or bfloat16 producer pays one more 262 MB pass there).
@@ -218,6 +219,24 @@ int ctc_amd_loss_grad_ex(int kind, int wrt,
                          float *loss, void *grad, int grad_dtype, int64_t grad_stride_b, int64_t grad_stride_t,
                          const float *d_loss,
                          void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * ctc_amd_loss_grad_ex for PACKED (ragged) batches: no padding frames in memory.  Utterance b owns the logit_length[b] rows
+ * row_offsets[b] .. row_offsets[b] + logit_length[b] - 1 of a [total_rows][row_stride] tensor (row_stride >= V elements, the
+ * token axis contiguous); the gradient has the same packing (and its own element type).  T is max(logit_length) (a bound is
+ * fine: it sizes the workspace, CTC_AMD_WS_LOSS_GRAD).  row_offsets is a DEVICE array of B int64; the ranges must not overlap.
+ * Rows beyond logit_length[b] do not exist and are neither read nor written.  Runs the three-kernel pipeline.
+ * Replaces: the [batch, max_length, num_tokens] padding the reference requires of its caller (base_loss.py:105-138) together
+ * with the masks that undo it (base_loss.py:283-298).  SURVEY.md section 8(f) rank 3 (producer formats).
+ */
+int ctc_amd_loss_grad_packed(int kind, int wrt,
+                             const void *logits, int logits_dtype, const int64_t *row_offsets, int64_t row_stride,
+                             const int32_t *labels, int label_stride,
+                             const int32_t *label_length, const int32_t *logit_length, int blank_index,
+                             int B, int T, int V, int U,
+                             float *loss, void *grad, int grad_dtype, int64_t grad_row_stride,
+                             const float *d_loss,
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * ctc_amd_loss_grad_ex that also accumulates what a training loop takes from the losses, without a launch of its own.

@@ -12,12 +12,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTC_AMD_LIB", os.path.join(_HERE, "libctc_amd.so"))  # override: kernel experiments only
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 CLASSIC, SIMPLIFIED = 0, 1
 WRT_LOGITS, WRT_LOGPROBS = 0, 1
 WS_LOSS_GRAD, WS_ALPHA_BETA, WS_HESSIAN, WS_HVP, WS_LOSS_GRAD_LOGITS = 0, 1, 2, 3, 4
 OK, EINVAL, EWORKSPACE, EHIP, ELABEL = 0, -1, -2, -3, -4
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 
 _c_int, _c_void_p, _c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 
@@ -45,6 +45,11 @@ SIGNATURES = {
                                       _c_int, _c_int, _c_int, _c_int,                                   # B, T, V, U
                                       _c_void_p, _c_void_p, _c_int, ctypes.c_int64, ctypes.c_int64,    # loss, grad, dtype, strides
                                       _c_void_p, _c_void_p, _c_size_t, _c_void_p]),                     # d_loss, ws, bytes, stream
+    "ctc_amd_loss_grad_packed": (_c_int, [_c_int, _c_int, _c_void_p, _c_int, _c_void_p, ctypes.c_int64,        # kind, wrt, logits, dtype, row_offsets, row_stride
+                                          _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int,                  # labels .. blank_index
+                                          _c_int, _c_int, _c_int, _c_int,                                    # B, T, V, U
+                                          _c_void_p, _c_void_p, _c_int, ctypes.c_int64,                      # loss, grad, dtype, grad row stride
+                                          _c_void_p, _c_void_p, _c_size_t, _c_void_p]),                      # d_loss, ws, bytes, stream
     "ctc_amd_loss_grad_sum": (_c_int, [_c_int, _c_int, _c_void_p, _c_int, ctypes.c_int64, ctypes.c_int64,
                                        _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int,
                                        _c_int, _c_int, _c_int, _c_int,

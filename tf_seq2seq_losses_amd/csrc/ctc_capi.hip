@@ -32,6 +32,7 @@ inline bool fused5_eligible(const Problem &p, const Layout &L) {
   // (bfloat16 needs 8-byte aligned rows: V and the strides multiples of 4; float32 takes any V <= 256 and any stride)
   // (U <= 512: eight label positions per lane, 3-frame blocks)
   return p.wrt == 0 && (p.V <= 512 || (p.V <= 1024 && L.NL <= 2)) && L.NL <= 8 && p.B > 0 && p.T > 0 && p.xdtype == p.gdtype &&
+         p.xdtype <= 1 && p.row0 == nullptr &&  // (float16 and packed batches: three-kernel pipeline)
          (p.xdtype == 0 || (((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0 && (p.align_bits & 7) == 0));
 }
 inline hipError_t run_fused5(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, bool only_flagged, hipStream_t st) {
@@ -341,8 +342,8 @@ int ctc_amd_loss_grad_ex(int kind, int wrt, const void *logits, int logits_dtype
   int rc = check_common(kind, wrt, static_cast<const float *>(logits), labels, label_stride, label_length, logit_length,
                         blank_index, B, T, V, U);
   if (rc) return rc;
-  if ((logits_dtype != CTC_AMD_F32 && logits_dtype != CTC_AMD_BF16) || (grad_dtype != CTC_AMD_F32 && grad_dtype != CTC_AMD_BF16))
-    return fail(CTC_AMD_EINVAL, "dtype must be CTC_AMD_F32 or CTC_AMD_BF16 (logits %d, grad %d)", logits_dtype, grad_dtype);
+  if (logits_dtype < CTC_AMD_F32 || logits_dtype > CTC_AMD_F16 || grad_dtype < CTC_AMD_F32 || grad_dtype > CTC_AMD_F16)
+    return fail(CTC_AMD_EINVAL, "dtype must be CTC_AMD_F32, CTC_AMD_BF16 or CTC_AMD_F16 (logits %d, grad %d)", logits_dtype, grad_dtype);
   if (B == 0) return CTC_AMD_OK;
   // rows must not overlap: |stride_t| >= V, and the batch stride must step over whole rows in either nesting order
   if (logits_stride_t < V || logits_stride_b < V || (grad && (grad_stride_t < V || grad_stride_b < V)))
@@ -355,6 +356,28 @@ int ctc_amd_loss_grad_ex(int kind, int wrt, const void *logits, int logits_dtype
   return loss_grad_impl(p, loss, grad, d_loss, workspace, workspace_bytes, stream);
 }
 
+int ctc_amd_loss_grad_packed(int kind, int wrt, const void *logits, int logits_dtype, const int64_t *row_offsets, int64_t row_stride,
+                             const int32_t *labels, int label_stride, const int32_t *label_length, const int32_t *logit_length,
+                             int blank_index, int B, int T, int V, int U, float *loss, void *grad, int grad_dtype,
+                             int64_t grad_row_stride, const float *d_loss, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = check_common(kind, wrt, static_cast<const float *>(logits), labels, label_stride, label_length, logit_length,
+                        blank_index, B, T, V, U);
+  if (rc) return rc;
+  if (logits_dtype < CTC_AMD_F32 || logits_dtype > CTC_AMD_F16 || grad_dtype < CTC_AMD_F32 || grad_dtype > CTC_AMD_F16)
+    return fail(CTC_AMD_EINVAL, "dtype must be CTC_AMD_F32, CTC_AMD_BF16 or CTC_AMD_F16 (logits %d, grad %d)", logits_dtype, grad_dtype);
+  if (B == 0) return CTC_AMD_OK;
+  if (!row_offsets) return fail(CTC_AMD_EINVAL, "null row_offsets pointer");
+  if (row_stride < V || (grad && grad_row_stride < V))
+    return fail(CTC_AMD_EINVAL, "row strides smaller than a row of V=%d elements (logits %lld, grad %lld)", V, (long long)row_stride,
+                (long long)grad_row_stride);
+  ctc::Problem p = make_problem(kind, wrt, static_cast<const float *>(logits), labels, label_stride, label_length, logit_length,
+                                blank_index, B, T, V, U);
+  p.xsb = 0; p.xst = row_stride; p.xdtype = logits_dtype;
+  p.gsb = 0; p.gst = grad ? grad_row_stride : V; p.gdtype = grad_dtype;
+  p.row0 = reinterpret_cast<const long long *>(row_offsets);
+  return loss_grad_impl(p, loss, grad, d_loss, workspace, workspace_bytes, stream);
+}
+
 int ctc_amd_loss_grad_sum(int kind, int wrt, const void *logits, int logits_dtype, int64_t logits_stride_b,
                           int64_t logits_stride_t, const int32_t *labels, int label_stride, const int32_t *label_length,
                           const int32_t *logit_length, int blank_index, int B, int T, int V, int U, float *loss, void *grad,
@@ -364,8 +387,8 @@ int ctc_amd_loss_grad_sum(int kind, int wrt, const void *logits, int logits_dtyp
                         blank_index, B, T, V, U);
   if (rc) return rc;
   if (!sum2) return fail(CTC_AMD_EINVAL, "null sum2 pointer");
-  if ((logits_dtype != CTC_AMD_F32 && logits_dtype != CTC_AMD_BF16) || (grad_dtype != CTC_AMD_F32 && grad_dtype != CTC_AMD_BF16))
-    return fail(CTC_AMD_EINVAL, "dtype must be CTC_AMD_F32 or CTC_AMD_BF16 (logits %d, grad %d)", logits_dtype, grad_dtype);
+  if (logits_dtype < CTC_AMD_F32 || logits_dtype > CTC_AMD_F16 || grad_dtype < CTC_AMD_F32 || grad_dtype > CTC_AMD_F16)
+    return fail(CTC_AMD_EINVAL, "dtype must be CTC_AMD_F32, CTC_AMD_BF16 or CTC_AMD_F16 (logits %d, grad %d)", logits_dtype, grad_dtype);
   if (logits_stride_t < V || logits_stride_b < V || (grad && (grad_stride_t < V || grad_stride_b < V)))
     return fail(CTC_AMD_EINVAL, "strides smaller than a row of V=%d elements", V);
   ctc::Problem p = make_problem(kind, wrt, static_cast<const float *>(logits), labels, label_stride, label_length, logit_length,
@@ -391,8 +414,8 @@ int ctc_amd_grad_resume(int kind, int wrt, const void *logits, int logits_dtype,
   int rc = check_common(kind, wrt, static_cast<const float *>(logits), labels, label_stride, label_length, logit_length,
                         blank_index, B, T, V, U);
   if (rc) return rc;
-  if ((logits_dtype != CTC_AMD_F32 && logits_dtype != CTC_AMD_BF16) || (grad_dtype != CTC_AMD_F32 && grad_dtype != CTC_AMD_BF16))
-    return fail(CTC_AMD_EINVAL, "dtype must be CTC_AMD_F32 or CTC_AMD_BF16 (logits %d, grad %d)", logits_dtype, grad_dtype);
+  if (logits_dtype < CTC_AMD_F32 || logits_dtype > CTC_AMD_F16 || grad_dtype < CTC_AMD_F32 || grad_dtype > CTC_AMD_F16)
+    return fail(CTC_AMD_EINVAL, "dtype must be CTC_AMD_F32, CTC_AMD_BF16 or CTC_AMD_F16 (logits %d, grad %d)", logits_dtype, grad_dtype);
   if (!grad) return fail(CTC_AMD_EINVAL, "null grad pointer");
   if (B == 0) return CTC_AMD_OK;
   if (logits_stride_t < V || logits_stride_b < V || grad_stride_t < V || grad_stride_b < V)

@@ -177,7 +177,10 @@ struct Problem {
   // token axis is contiguous) and their element types (0 = float32, 1 = bfloat16).  Everything else reads `logits`
   // as contiguous float32 [B,T,V].
   long xsb, xst, gsb, gst;
-  int xdtype, gdtype;
+  int xdtype, gdtype;  // 0 = float32, 1 = bfloat16, 2 = float16 (the last: three-kernel pipeline only)
+  // packed (ragged) batches, ctc_amd_loss_grad_packed: first row of every utterance in logits and gradient (rows of xst / gst
+  // elements; xsb / gsb are then unused and rows beyond logit_length do not exist).  Three-kernel pipeline only.
+  const long long *row0 = nullptr;
   // ctc_amd_loss_grad_sum: [0] += sum of the finite losses in units of 2^-20 (integer adds: the same bits whatever the order),
   // [1] += their number; sum_zero (the buffer of the NEXT step, if any) is cleared by this call
   long long *sum_out = nullptr, *sum_zero = nullptr;
@@ -188,6 +191,19 @@ struct Problem {
   // paths need aligned bases as well as aligned strides; otherwise the element-wise paths run
   int align_bits = 0;
 };
+
+// element offset of row (b, t) of the logits / of the gradient
+__device__ __forceinline__ long logits_off(const Problem &p, int b, int t) {
+  return (p.row0 ? (long)p.row0[b] * p.xst : (long)b * p.xsb) + (long)t * p.xst;
+}
+__device__ __forceinline__ long grad_off(const Problem &p, int b, int t) {
+  return (p.row0 ? (long)p.row0[b] * p.gst : (long)b * p.gsb) + (long)t * p.gst;
+}
+// float16 <-> float32 (v_cvt_f32_f16 / v_cvt_f16_f32, round to nearest even)
+__device__ __forceinline__ float f16_to_f32(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ unsigned short f32_to_f16(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+// 16-bit element of type dt (1 = bfloat16, 2 = float16) <-> float32
+__device__ __forceinline__ float h16_to_f32(unsigned short h, int dt) { return dt == 2 ? f16_to_f32(h) : __uint_as_float((unsigned)h << 16); }
 
 // bfloat16 <-> float32 (round to nearest even on the way back)
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }

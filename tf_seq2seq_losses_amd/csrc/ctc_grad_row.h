@@ -28,7 +28,7 @@ __device__ __forceinline__ void grad_row(const Problem &p, const Layout &L, cons
   constexpr int CH = 1024;
   const int V = p.V, UP = L.UP;
   const long row = (long)b * p.T + t;
-  float *g = grad + (long)b * p.gsb + (long)t * p.gst;
+  float *g = grad + grad_off(p, b, t);
   typedef float v4f __attribute__((ext_vector_type(4)));
   auto gput4 = [&](int k, float4 r) {
     v4f v = {r.x, r.y, r.z, r.w};
@@ -36,11 +36,12 @@ __device__ __forceinline__ void grad_row(const Problem &p, const Layout &L, cons
   };
   const int len = v1_clampi(p.logit_length[b], 0, p.T);
   const int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
+  if (t >= len && p.row0 != nullptr) return;  // packed batches: rows beyond the length do not exist
   bool zero = t >= len || ll > p.U;  // padded frames, contract violations: exactly zero (base_loss.py:283-298)
   const int32_t *lab = p.labels + (long)b * p.label_stride;
   float *qf = reinterpret_cast<float *>(qtab);
   float inv = 0.f, qblank = 0.f;
-  const float *x = p.logits + (long)b * p.xsb + (long)t * p.xst;
+  const float *x = p.logits + logits_off(p, b, t);
   const bool wrt_logits = p.wrt == 0;
   // the first 1024 columns of the logits row are requested before anything else: they do not depend on the chains, and the
   // polls and the lattice rows below are three dependent round trips through a saturated memory system

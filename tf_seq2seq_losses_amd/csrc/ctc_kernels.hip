@@ -141,12 +141,15 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
   const int b = (int)(row / p.T), t = (int)(row % p.T);
   const int V = p.V, UP = L.UP;
   // output row in the consumer's format: float32 or bfloat16, any batch/time stride
-  const long goff = (long)b * p.gsb + (long)t * p.gst;
+  const long goff = grad_off(p, b, t);
   float *g = grad + goff;                                                        // valid for float32 only
-  unsigned short *gh = reinterpret_cast<unsigned short *>(grad) + goff;           // valid for bfloat16 only
+  unsigned short *gh = reinterpret_cast<unsigned short *>(grad) + goff;           // valid for bfloat16 / float16 only
   const bool gbf = p.gdtype != 0;
   // outputs are written once and not read here: non-temporal stores
-  auto gput = [&](int k, float v) { if (gbf) __builtin_nontemporal_store(f32_to_bf16(v), gh + k); else __builtin_nontemporal_store(v, g + k); };
+  auto gput = [&](int k, float v) {
+    if (gbf) __builtin_nontemporal_store(p.gdtype == 2 ? f32_to_f16(v) : f32_to_bf16(v), gh + k);
+    else __builtin_nontemporal_store(v, g + k);
+  };
   auto gput4 = [&](int k, float4 r) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     v4f v = {r.x, r.y, r.z, r.w};
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
   const bool gvec = !gbf && ((V | goff) & 3) == 0 && (p.align_bits & 15) == 0;
   const int len = clampi(p.logit_length[b], 0, p.T);
   const double lp = logp[b];
+  if (t >= len && p.row0 != nullptr) return;  // packed batches: rows beyond the length do not exist
   if (t >= len || lp == -INFINITY) {
     // padded frames and infeasible samples: exactly zero (base_loss.py:283-298)
     if (gvec) for (int k = lane * 4; k < V; k += 256) gput4(k, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
   if (p.wrt == 0) {
     // g_x[k] = d_loss * (softmax(x)[k] * sum_k' post[k'] - post[k]), sum_k' post = 1 on a valid frame of a feasible
     // sample (TF autodiff of tools.py:37-39 applied to base_loss.py:150-153)
-    const long xoff = (long)b * p.xsb + (long)t * p.xst;
+    const long xoff = logits_off(p, b, t);
     const float *x = p.logits + xoff;
     const unsigned short *xh = reinterpret_cast<const unsigned short *>(p.logits) + xoff;
     const bool bf = p.xdtype != 0;
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void grad_kernel(Problem p, Layout L, const fl
       }
     } else {
       for (int k = lane; k < V; k += 64) {
-        const float xv = bf ? bf16_to_f32(xh[k]) : x[k];
+        const float xv = bf ? h16_to_f32(xh[k], p.xdtype) : x[k];
         gput(k, dl * (fexp2((xv - mx) * LOG2E - l2s) - bin[k]));
       }
     }
@@ -491,7 +495,7 @@ hipError_t run_emit_scan(const Problem &p, const Layout &L, char *ws, float *los
   double *logp = reinterpret_cast<double *>(ws + L.off_logp);
   const long rows = (long)p.B * p.T;
   if (rows > 0) {
-    const bool four = p.V <= 512 && p.xdtype == 0 && (p.align_bits & 15) == 0 && ((p.V | p.xsb | p.xst) & 3) == 0;
+    const bool four = p.V <= 512 && p.xdtype == 0 && p.row0 == nullptr && (p.align_bits & 15) == 0 && ((p.V | p.xsb | p.xst) & 3) == 0;
     const long waves = (long)p.B * ((p.T + 3) / 4);
     if (four) hipLaunchKernelGGL(emit4_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, p, L, emis);
     else hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, L, emis);

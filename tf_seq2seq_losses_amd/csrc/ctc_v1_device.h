@@ -21,11 +21,11 @@ __device__ __forceinline__ void emit_row(const Problem &p, const Layout &L, floa
   const int ll = p.label_length[b] < 0 ? 0 : p.label_length[b];
   const int V = p.V;
   // element accessor of this frame's row: float32 or bfloat16, any batch/time stride (producer formats)
-  const long xoff = (long)b * p.xsb + (long)t * p.xst;
+  const long xoff = logits_off(p, b, t);
   const float *x = p.logits + xoff;                                                   // valid for float32 only
-  const unsigned short *xh = reinterpret_cast<const unsigned short *>(p.logits) + xoff;  // valid for bfloat16 only
+  const unsigned short *xh = reinterpret_cast<const unsigned short *>(p.logits) + xoff;  // valid for bfloat16 / float16 only
   const bool bf = p.xdtype != 0;
-  auto xat = [&](int k) -> float { return bf ? bf16_to_f32(xh[k]) : x[k]; };
+  auto xat = [&](int k) -> float { return bf ? h16_to_f32(xh[k], p.xdtype) : x[k]; };
 
   // the label tokens are requested FIRST, beside the row itself: fetched after the statistics they made the gathers below two
   // dependent round trips (label -> token -> logit) with nothing else of the wavefront in flight.  (The gathers themselves stay

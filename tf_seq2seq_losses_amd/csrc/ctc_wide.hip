@@ -526,7 +526,7 @@ static hipError_t launch_kind(const Problem &p, const Layout &L, char *ws, float
 // float32 rows, 16-byte aligned, V a multiple of 4 (the accesses of grad_row), labels of up to 256 positions (the LDS rings of
 // a chain workgroup hold 8..16 rows), a gradient wanted
 bool wide_eligible(const Problem &p, const Layout &L) {
-  return p.V > 1024 && L.NL <= 4 && p.xdtype == 0 && p.gdtype == 0 && (p.align_bits & 15) == 0 && ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0 &&
+  return p.V > 1024 && L.NL <= 4 && p.xdtype == 0 && p.gdtype == 0 && p.row0 == nullptr && (p.align_bits & 15) == 0 && ((p.V | p.xsb | p.xst | p.gsb | p.gst) & 3) == 0 &&
          L.UP <= CTC_AMD_MAX_U && p.B > 0 && p.T > 0 &&
          wide::sync_bytes(p.B, p.T) <= (size_t)p.B * 2 * L.nslot * 64 * 4;
 }

@@ -49,7 +49,8 @@ def _blank(blank_index) -> int:
 def _verify_inputs(labels, x, label_length, logit_length):
     """base_loss.py:129-138 : same assertions, same exception type (AssertionError)."""
     assert x.dim() == 3
-    assert x.dtype in (torch.float32, torch.bfloat16)  # the reference takes float32 only; bfloat16 is an extension (DESIGN.md)
+    # the reference takes float32 only; bfloat16 / float16 activations are an extension (DESIGN.md 5.5)
+    assert x.dtype in (torch.float32, torch.bfloat16, torch.float16)
     assert labels.dim() == 2
     assert logit_length.dim() == 1
     assert label_length.dim() == 1

@@ -43,7 +43,7 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
-_DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+_DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
 
 
 class Prepared:
@@ -117,6 +117,8 @@ def _loss_grad_selector(wrt: int, p: "Prepared") -> int:
         return _lib.WS_LOSS_GRAD
     x = p.x
     if x.dtype == torch.bfloat16 and ((p.V | x.stride(0) | x.stride(1)) & 3 or x.data_ptr() & 7):
+        return _lib.WS_LOSS_GRAD
+    if x.dtype == torch.float16:  # read by the three-kernel pipeline only
         return _lib.WS_LOSS_GRAD
     return _lib.WS_LOSS_GRAD_LOGITS
 
@@ -194,6 +196,38 @@ def loss_grad(kind: int, wrt: int, p: Prepared, want_grad: bool, d_loss: Optiona
             rc = lib.ctc_amd_loss_grad(*p.common(kind, wrt), _ptr(loss), _ptr(grad), _ptr(d_loss),
                                        ws.data_ptr(), ws.numel(), _stream(p.device))
     _lib.check(rc, "ctc_amd_loss_grad")
+    return loss, grad
+
+
+def loss_grad_packed(kind: int, wrt: int, labels: torch.Tensor, x: torch.Tensor, row_offsets: torch.Tensor,
+                     label_length: torch.Tensor, logit_length: torch.Tensor, blank_index: int, max_length: int,
+                     U: Optional[int] = None, want_grad: bool = True, d_loss: Optional[torch.Tensor] = None):
+    """Packed (ragged) batch, ctc_amd_loss_grad_packed: `x` is [total_rows, V] (float32 / bfloat16 / float16, rows contiguous
+    in the token axis), utterance b owns the rows row_offsets[b] .. row_offsets[b] + logit_length[b] - 1; the gradient comes
+    back with the same packing and element type.  max_length >= max(logit_length) sizes the workspace."""
+    lib = _lib.load()
+    _require_gpu(x)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in _DTYPES
+    dev = x.device
+    B, V, T = int(labels.shape[0]), int(x.shape[1]), int(max_length)
+    i32 = lambda t: t.to(device=dev, dtype=torch.int32).contiguous()
+    labels, label_length, logit_length = i32(labels), i32(label_length), i32(logit_length)
+    row_offsets = row_offsets.to(device=dev, dtype=torch.int64).contiguous()
+    U = int(labels.shape[1]) if U is None else int(U)
+    loss = torch.empty(B, dtype=torch.float32, device=dev)
+    grad = torch.zeros_like(x) if want_grad else None  # (rows no utterance owns stay zero)
+    if B == 0:
+        return loss, grad
+    ws = torch.empty(max(_lib.workspace_bytes(_lib.WS_LOSS_GRAD, kind, B, T, V, U), 1), dtype=torch.uint8, device=dev)
+    if d_loss is not None:
+        d_loss = d_loss.to(device=dev, dtype=torch.float32).contiguous()
+    dt = _DTYPES[x.dtype]
+    with _on_device(dev):
+        rc = lib.ctc_amd_loss_grad_packed(kind, wrt, _ptr(x), dt, _ptr(row_offsets), x.stride(0), _ptr(labels), int(labels.shape[1]),
+                                          _ptr(label_length), _ptr(logit_length), int(blank_index), B, T, V, U, _ptr(loss),
+                                          _ptr(grad), dt, grad.stride(0) if grad is not None else V, _ptr(d_loss),
+                                          ws.data_ptr(), ws.numel(), _stream(dev))
+    _lib.check(rc, "ctc_amd_loss_grad_packed")
     return loss, grad
 
 
