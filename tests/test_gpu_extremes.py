@@ -50,8 +50,9 @@ def test_long_utterances(kind):
     """T = 5000 (five times the north-star length): 209 blocks per side in the fused kernel.  The linear-domain lattice
     carries a RELATIVE rounding of 2^-24 per operation: measured max|dgrad| 3.0e-6 here (round 2) -- the 1e-4 bar holds.
     The log-domain kernel, which redoes utterances the linear one flags, carries ~4e-6 of ABSOLUTE rounding per step on
-    renormalised logarithms of magnitude ~100: measured 1.34e-3 at this length (2.4e-4 at T = 1000), bound 2e-3; the loss
-    (offsets in double) keeps its 1e-4 relative bound on both."""
+    renormalised logarithms of magnitude ~100: r02 measured 1.34e-3 at this length (2.4e-4 at T = 1000).  Since r03 its posteriors are
+    normalised by the frame's own mass, which divides the common part of that rounding out: measured 1.9e-4 here (classic; 2.4e-5
+    simplified) and 4.3e-5 at T = 1000, bound 3e-4; the loss (offsets in double) keeps its 1e-4 relative bound on both."""
     rng = np.random.default_rng(2)
     B, T, V, U = 3, 5000, 256, 128
     logits = rng.standard_normal((B, T, V)).astype(np.float32)
@@ -61,7 +62,7 @@ def test_long_utterances(kind):
     from tf_seq2seq_losses_amd import _lib
     _lib.debug_override("pipeline", "fused5")
     try:
-        _check(kind, logits, labels, ll, tl, tol_g=2e-3)
+        _check(kind, logits, labels, ll, tl, tol_g=3e-4)
     finally:
         _lib.debug_override("pipeline", "")
 

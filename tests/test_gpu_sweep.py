@@ -60,11 +60,8 @@ def test_shape_sweep(kind, T, U, V, B):
     if fin.any():
         assert (np.abs(lossn[fin] - rl[fin]) / np.maximum(1.0, np.abs(rl[fin]))).max() < TOL
     assert np.isfinite(gradn).all()
-    # The 1e-4 bar holds for every utterance the linear-domain kernel keeps.  Sharp logits (the x4 cases) on a nearly forced
-    # alignment exceed its range; they are redone in float32 LOG space, which resolves ~1e-7 * |log-probability| per
-    # operation: when the loss runs into the thousands of nats the posteriors carry a few 1e-4 (measured up to 2.4e-4)
-    # (read from the kernel's own flag word: an UNFLAGGED utterance is held to 1e-4 whatever its loss)
+    # The 1e-4 bar holds for every utterance, whichever domain computed it.  (r02 allowed 5e-4 for utterances the linear-domain
+    # kernel hands to its log-domain roles when the loss runs into the thousands of nats -- measured up to 2.4e-4; since r03 those
+    # roles normalise a frame's posteriors by the frame's own mass and stay in the 1e-5 class.)
     for b in range(B):
-        kept = flags is not None and flags[b] == 0
-        big = bool(fin[b]) and abs(rl[b]) > 500
-        assert np.abs(gradn[b] - rg[b]).max() < (TOL if (kept or not big) else 5e-4), (b, None if flags is None else int(flags[b]))
+        assert np.abs(gradn[b] - rg[b]).max() < TOL, (b, None if flags is None else int(flags[b]))

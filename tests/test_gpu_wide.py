@@ -119,7 +119,7 @@ def test_wide_rows_sum_to_zero_and_match_v1_at_the_bench_size():
     err, err1 = np.abs(grad[sel] - rg).max(), np.abs(grad1[sel] - rg).max()
     print(f"gradient error vs float64 at T = 1000: wide {err:.2e}, three-kernel pipeline {err1:.2e}")
     assert err < TOL
-    assert np.abs(grad - grad1).max() < 5e-4  # (the three-kernel pipeline divides by the P of a 1000-frame float32 sweep)
+    assert err1 < TOL and np.abs(grad - grad1).max() < 2 * TOL  # (each within TOL of the oracle)
     assert np.abs(grad.sum(axis=2)).max() < 2e-5
     for b in range(B):
         assert not grad[b, tl[b]:].any()

@@ -441,6 +441,20 @@ struct Side {
       qb += fexp2(s1[j]);
       qt[j] = fexp2(s2[j]);
     }
+    // Normalised by the frame's OWN mass (= 1 when the log P of the meeting point and both sweeps are exact; the invariant of the
+    // reference's tests/test_classic_ctc_loss.py:146-167): what a long float32 log-domain sweep has accumulated in rounding enters
+    // every posterior of a frame as the same factor -- dividing it out took this tier's gradient error at T = 1000 with sharp
+    // logits from ~1e-3 to the 1e-4 class (r03; the three-kernel pipeline does the same, ctc_grad_row.h).
+    {
+      float tot = qb;
+#pragma unroll
+      for (int j = 0; j < NL; ++j) tot += qt[j];
+      const float mass = wave_sum_dpp(tot);
+      const float f = (mass > 0.f && mass < INFINITY) ? 1.0f / mass : 1.0f;
+      qb *= f;
+#pragma unroll
+      for (int j = 0; j < NL; ++j) qt[j] *= f;
+    }
     // (no wave barrier needed: LDS ops of one wave execute in order and may-alias accesses keep program order)
     // Scatter by label with FIXED-POINT integer atomics.  ds_add_f32 turned out to be the bottleneck of the whole kernel
     // on gfx950 (it throttles every wavefront of the CU that touches LDS; replacing it with a plain store -- wrong for
@@ -484,14 +498,24 @@ struct Side {
 #pragma unroll
     for (int q = 0; q < VPL; ++q) *reinterpret_cast<uint4 *>(bins + 256 * q + lane * 4) = make_uint4(0u, 0u, 0u, 0u);  // (same type as the atomics and the read: float stores may be reordered against them)
     float qb = (lane == 0) ? fexp2(s0) : 0.f;
+    float qt[NL], tot;
     char *bb = reinterpret_cast<char *>(bins);
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       qb += fexp2(s1[j]);
-      if (tokoff[j] != 4 * V) atomicAdd(reinterpret_cast<unsigned *>(bb + tokoff[j]), (unsigned)(fexp2(s2[j]) + 0.5f));
+      qt[j] = fexp2(s2[j]);
     }
+    tot = qb;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) tot += qt[j];
+    // normalised by the frame's own mass (2^30 in these units when everything is exact; see grad_row)
+    const float mass = wave_sum_dpp(tot);
+    const float f = (mass > 0.f && mass < INFINITY) ? 1073741824.0f / mass : 1.0f;
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
+      if (tokoff[j] != 4 * V) atomicAdd(reinterpret_cast<unsigned *>(bb + tokoff[j]), (unsigned)(qt[j] * f + 0.5f));
     wave_lds_fence();  // the bins read below were written by other lanes
-    qb = wave_sum_dpp(qb);  // blank posterior, in units of 2^-30
+    qb = wave_sum_dpp(qb) * f;  // blank posterior, in units of 2^-30
     const float c1 = -dl * 9.31322574615478515625e-10f;
 #pragma unroll
     for (int q = 0; q < VPL; ++q) {
