@@ -170,7 +170,8 @@ def test_hvp_north_star_size_finite_differences(kind):
     against the directional derivative of the float64 oracle's gradient (Richardson-extrapolated central differences: error far
     below 1e-6 of max|Hv|).  The fused linear-domain kernel (ctc_hvp_fused.hip) is held to north_star's 1e-4 of max|Hv|; the
     log-domain pipeline it replaced at this shape (still the route of flagged utterances, forced here through the override)
-    measured 2.3e-4 / 2.9e-4 and keeps its 4.5e-4 bound.  Symmetry <u,Hv> = <v,Hu> on the scale |v| |Hu|: 2e-6."""
+    measured 2.3e-4 / 2.9e-4 in r02; since r03 it takes posteriors and their tangents relative to the frame's own mass
+    (ctc_hvp_device.h) and is held to the same 1e-4.  Symmetry <u,Hv> = <v,Hu> on the scale |v| |Hu|: 2e-6."""
     from tf_seq2seq_losses_amd import ops, _lib
     B, T, U, V = 4, 1000, 128, 256
     rng = np.random.default_rng(11)
@@ -191,7 +192,9 @@ def test_hvp_north_star_size_finite_differences(kind):
     finally:
         _lib.debug_override("hvp", "")
     for b in range(B):
-        assert np.abs(old[b] - fd[b]).max() < 4.5e-4 * np.abs(fd[b]).max(), b
+        e = np.abs(old[b] - fd[b]).max() / np.abs(fd[b]).max()
+        print(f"log-domain HVP pipeline, {kind}, utterance {b}: {e:.2e} of max|Hv|")
+        assert e < 1e-4, (b, e)
     # <u, Hv> = <v, Hu> at this size (256k-term inner products: compared on the scale |v| |Hu|)
     u = rng.standard_normal((B, T, V)).astype(np.float32)
     hu = ops.hvp(ops.KINDS[kind], _lib.WRT_LOGITS, _prep(inp), _t(u))[2].double()
@@ -245,7 +248,7 @@ def test_fused_hvp_against_the_oracle_and_the_log_domain_pipeline(kind, B, T, V,
     for b in range(B):
         scale = max(1e-3, np.abs(fd[b]).max())
         assert np.abs(outn[b] - fd[b]).max() < TOL * max(1.0, scale), (b, np.abs(outn[b] - fd[b]).max(), scale)
-        assert np.abs(out1n[b] - fd[b]).max() < 4.5e-4 * max(1.0, scale), b
+        assert np.abs(out1n[b] - fd[b]).max() < TOL * max(1.0, scale), b
         assert np.all(outn[b, int(inp["logit_length"][b]):] == 0)
         if not fin[b]:
             assert np.all(outn[b] == 0)

@@ -1,8 +1,9 @@
 """Soak run of the Hessian-vector product (test infrastructure): random shapes inside the fused kernel's range through
 ctc_amd_hvp, the first utterances of each compared with the Richardson-extrapolated directional derivative of the float64
-NumPy oracle's gradient -- 1e-4 of max|Hv| for utterances the fused kernel kept in the linear domain (its flag word), 2e-3 for
+NumPy oracle's gradient -- 1e-4 of max|Hv| for utterances the fused kernel kept in the linear domain (its flag word) and, since the log-domain rows take
+posteriors and tangents relative to the frame's own mass, also for
 those it redid in the log domain (sharp logits: the float32 log-domain recursion's own accuracy) -- and with the log-domain
-pipeline forced through the override (2e-3).  usage: python tests/tools/soak_hvp.py [seconds]"""
+pipeline forced through the override (2e-4).  usage: python tests/tools/soak_hvp.py [seconds]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -39,7 +40,7 @@ while time.time() - t0 < budget:
     assert torch.equal(torch.isfinite(loss), torch.isfinite(loss1)), (B, T, V, U, kind, blank)
     scale = max(1.0, float(out1.abs().max()))
     err = float((out - out1).abs().max()) / scale
-    assert err < 2e-3, (B, T, V, U, kind, blank, err)
+    assert err < 2e-4, (B, T, V, U, kind, blank, err)  # (both within 1e-4 of the float64 derivative)
     worst_pair = max(worst_pair, err)
     if B * T * V < 400000 and T > 0:   # float64 check of the first utterances
         m = min(B, 3)
@@ -56,11 +57,11 @@ while time.time() - t0 < budget:
         for b in range(m):
             cls = "linear" if flags[b] == 0 else "redone"
             e = float(np.abs(on[b] - fd[b]).max()) / max(1.0, float(np.abs(fd[b]).max()))
-            assert e < (1e-4 if cls == "linear" else 2e-3), (cls, B, T, V, U, kind, blank, b, e, int(flags[b]))
+            assert e < 1e-4, (cls, B, T, V, U, kind, blank, b, e, int(flags[b]))  # (r02 / early r03: 2e-3 for redone utterances)
             worst[cls] = max(worst[cls], e); count[cls] += 1
     n += 1
     if time.time() - last > 5:
         print(f"{n} cases; vs float64: " + ", ".join(f"{k} {worst[k]:.2e} ({count[k]})" for k in worst) + f"; vs log-domain pipeline {worst_pair:.2e}", flush=True); last = time.time()
 print(f"hvp soak ok: {n} random cases in {time.time() - t0:.0f} s; worst error / max(1, max|Hv|) against the float64 directional derivative: "
-      + ", ".join(f"{k} {worst[k]:.2e} ({count[k]} utterances, bound {'1e-4' if k == 'linear' else '2e-3'})" for k in worst)
-      + f"; against the log-domain pipeline {worst_pair:.2e} (bound 2e-3)")
+      + ", ".join(f"{k} {worst[k]:.2e} ({count[k]} utterances, bound 1e-4)" for k in worst)
+      + f"; against the log-domain pipeline {worst_pair:.2e} (bound 2e-4)")

@@ -323,37 +323,64 @@ __device__ __forceinline__ void hvp_out_row(const Problem &p, const Layout &L, c
   const int32_t *lab = p.labels + (long)b * p.label_stride;
   const long ra_i = ((long)b * (p.T + 1) + (KIND == 0 ? t + 1 : t)) * L.SRS, rb_i = ((long)b * (p.T + 1) + t + 1) * L.SRS;
   const float *ra = alpha + ra_i, *rb = beta + rb_i, *da = dalpha + ra_i, *db = dbeta + rb_i;
-  const double scale = (double)ra[tailpos + 2] + (double)ra[tailpos + 3] + (double)rb[tailpos + 2] + (double)rb[tailpos + 3] - lp;
-  const float dlp = dlogp[b];
-  auto post = [&](float a_, float b_) -> float { return fminf(fexp2((float)((double)a_ + (double)b_ + scale)), 1.0f); };
-  auto post3 = [&](float a_, float b_, float c_) -> float { return fminf(fexp2((float)((double)a_ + (double)b_ + (double)c_ + scale)), 1.0f); };
-  float dblank = 0.f;
-  if constexpr (KIND == 0) {
-    for (int i = lane; i < UP; i += 64) {
+  // Posterior q_s = alpha beta / P of a lattice state and its tangent dq_s = q_s (d_s - dlogP), d_s = dalpha_s + dbeta_s (+ the
+  // tangents of the emissions between the two rows).  Both are taken relative to the frame's OWN mass (r03; the gradient kernels
+  // do the same, ctc_grad_row.h): q_s = e_s / sum_r e_r and dlogP = sum_r q_r d_r -- identities that hold for every frame (every
+  // alignment passes through exactly one state per frame), so the row offsets cancel before anything is added, the posterior
+  // tangents of a frame sum to zero exactly, and what a 1000-step float32 sweep has accumulated in rounding -- in the values and in
+  // the common component of the tangents -- drops out (error against float64 at T = 1000: 2.3-2.9e-4 -> the 1e-5 class).
+  // Three passes over the four rows (L1 hits): maximum; mass and mean tangent; scatter.
+  (void)dlogp;
+  const float *er = emis + row * (long)L.ERS, *der = demis + row * (long)L.ERS;
+  const float bl = (KIND == 1) ? er[UP] : 0.f, dbl = (KIND == 1) ? der[UP] : 0.f;
+  // (log2 weight, tangent) of the blank part and of the token part of label position i
+  auto terms = [&](int i, float &tb, float &db_, float &tt, float &dt_) {
+    if constexpr (KIND == 0) {
       const float2 a = *reinterpret_cast<const float2 *>(ra + 2 * i), bb = *reinterpret_cast<const float2 *>(rb + 2 * i);
-      const float2 ta = *reinterpret_cast<const float2 *>(da + 2 * i), tb = *reinterpret_cast<const float2 *>(db + 2 * i);
-      dblank += post(a.x, bb.x) * (ta.x + tb.x - dlp);
-      if (i < ll) {
-        const float dq = post(a.y, bb.y) * (ta.y + tb.y - dlp);
-        const int tok = (i < p.label_stride) ? lab[i] : p.blank;
-        if (tok >= 0 && tok < V && tok != p.blank) atomicAdd(&bin[tok], dq);
-      }
-    }
-    if (lane == 0) dblank += post(ra[2 * UP], rb[2 * UP]) * (da[2 * UP] + db[2 * UP] - dlp);
-  } else {
-    const float *er = emis + row * (long)L.ERS, *der = demis + row * (long)L.ERS;
-    const float bl = er[UP], dbl = der[UP];
-    for (int i = lane; i < UP; i += 64) {
+      const float2 ta = *reinterpret_cast<const float2 *>(da + 2 * i), tbb = *reinterpret_cast<const float2 *>(db + 2 * i);
+      tb = a.x + bb.x; db_ = ta.x + tbb.x;
+      tt = (i < ll) ? a.y + bb.y : NEG; dt_ = ta.y + tbb.y;
+    } else {
       const float ai = ra[i], bi = rb[i];  // state l = i+1 in both rows
-      dblank += post3(ai, bi, bl) * (da[i] + db[i] + dbl - dlp);
-      if (i < ll) {
-        const float aprev = (i == 0) ? ra[UP] : ra[i - 1], daprev = (i == 0) ? da[UP] : da[i - 1];
-        const float dq = post3(aprev, er[i], bi) * (daprev + der[i] + db[i] - dlp);
-        const int tok = (i < p.label_stride) ? lab[i] : p.blank;
-        if (tok >= 0 && tok < V && tok != p.blank) atomicAdd(&bin[tok], dq);
-      }
+      tb = ai + bi + bl; db_ = da[i] + db[i] + dbl;
+      const float aprev = (i == 0) ? ra[UP] : ra[i - 1], daprev = (i == 0) ? da[UP] : da[i - 1];
+      tt = (i < ll) ? aprev + er[i] + bi : NEG; dt_ = daprev + der[i] + db[i];
     }
-    if (lane == 0) dblank += post3(ra[UP], rb[UP], bl) * (da[UP] + db[UP] + dbl - dlp);
+  };
+  const float t0 = (KIND == 0) ? ra[2 * UP] + rb[2 * UP] : ra[UP] + rb[UP] + bl;          // the l = 0 state
+  const float d0 = (KIND == 0) ? da[2 * UP] + db[2 * UP] : da[UP] + db[UP] + dbl;
+  float m = t0;
+  for (int i = lane; i < UP; i += 64) {
+    float tb, db_, tt, dt_;
+    terms(i, tb, db_, tt, dt_);
+    m = fmaxf(m, fmaxf(tb, tt));
+  }
+  m = wave_max(m);
+  if (!(m > NEG_THR)) {  // no alignment passes through this frame (cannot happen on a feasible sample)
+    for (int k = lane; k < V; k += 64) __builtin_nontemporal_store(0.f, o + k);
+    return;
+  }
+  float ssum = 0.f, dsum = 0.f;
+  if (lane == 0) { const float e0 = fexp2(t0 - m); ssum = e0; dsum = e0 * d0; }
+  for (int i = lane; i < UP; i += 64) {
+    float tb, db_, tt, dt_;
+    terms(i, tb, db_, tt, dt_);
+    const float eb = fexp2(tb - m), et = fexp2(tt - m);  // (NEG - m underflows to 0)
+    ssum += eb + et;
+    dsum += eb * db_ + ((i < ll) ? et * dt_ : 0.f);
+  }
+  const float inv = 1.0f / wave_sum(ssum);  // the sum is >= 1: the maximum contributes 2^0
+  const float dmean = wave_sum(dsum) * inv;  // d log(mass) = dlogP
+  float dblank = (lane == 0) ? fexp2(t0 - m) * inv * (d0 - dmean) : 0.f;
+  for (int i = lane; i < UP; i += 64) {
+    float tb, db_, tt, dt_;
+    terms(i, tb, db_, tt, dt_);
+    dblank += fexp2(tb - m) * inv * (db_ - dmean);
+    if (i < ll) {
+      const float dq = fexp2(tt - m) * inv * (dt_ - dmean);
+      const int tok = (i < p.label_stride) ? lab[i] : p.blank;
+      if (tok >= 0 && tok < V && tok != p.blank) atomicAdd(&bin[tok], dq);
+    }
   }
   dblank = wave_sum(dblank);
   if (lane == 0) bin[p.blank] = dblank;
