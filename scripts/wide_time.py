@@ -1,6 +1,7 @@
 """Diagnostic: the one-launch wide-vocabulary tier (csrc/ctc_wide.hip) against the three-kernel pipeline at several shapes; HIP
 events around runs of calls; prints a markdown table (profiles/r03_wide_time.md).
-usage: python scripts/wide_time.py [B,T,U,V ...]"""
+usage: python scripts/wide_time.py [B,T,U,V ...] [diagN ...]   (diagN: timing diagnostics of the wide tier, bit set described in
+ctc_wide.hip; they exist in CTC_DIAG builds only: scripts/build_wide_variant.sh, then CTC_AMD_LIB=scratch/libctc_wide_diag.so)"""
 import os, sys, statistics as st
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

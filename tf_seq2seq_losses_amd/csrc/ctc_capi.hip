@@ -69,7 +69,9 @@ size_t hvp_fused_flags_offset(int kind, int B, int T, int U);
 int g_force_pipeline = 0;      // 0 = best eligible tier, 1 = v1 (three kernels), 5 = fused5 (log domain), 7 = wide (one persistent launch, V > 1024)
 int g_force_hessian_slab = 0;  // 1 = the general one-slab-per-wavefront Hessian kernel also for short labels
 int g_force_hvp_v1 = 0;        // 1 = the log-domain Hessian-vector pipeline also where the fused kernel applies
+#ifdef CTC_DIAG
 extern int g_wide_diag;        // timing diagnostics of the wide-vocabulary kernel (ctc_wide.hip; results are then meaningless)
+#endif
 int g_hvp_diag = 0;            // timing diagnostics of the fused kernel (ctc_hvp_fused.hip `mode`; results are then meaningless)
 hipError_t run_hvp(const Problem &p, const Layout &L, char *ws, const float *vec, float *out, hipStream_t st);
 hipError_t run_hvp_fused_classic(const Problem &p, const Layout &L, char *ws, const float *vec, float *loss, float *out, int mode, hipStream_t st);
@@ -185,12 +187,14 @@ int ctc_amd_debug_override(const char *key, const char *value) {
     ctc::g_hvp_diag = 0;
     return CTC_AMD_OK;
   }
+#ifdef CTC_DIAG
   if (!strcmp(key, "wide")) {  // timing diagnostics (scripts/wide_time.py): "" or "diag<number 0..31>"
     int v = 0;
     if (strcmp(value, "") && (sscanf(value, "diag%d", &v) != 1 || v < 0 || v > 31)) return fail(CTC_AMD_EINVAL, "wide override must be \"\" or \"diag0\"..\"diag31\", got \"%s\"", value);
     ctc::g_wide_diag = v;
     return CTC_AMD_OK;
   }
+#endif
   return fail(CTC_AMD_EINVAL, "unknown override key \"%s\"", key);
 }
 

@@ -37,7 +37,15 @@
 #include "ctc_grad_row.h"
 
 namespace ctc {
-int g_wide_diag = 0;  // timing diagnostics (ctc_amd_debug_override("wide", "diagN"): results are then meaningless)
+// Timing diagnostics (results are then meaningless) exist in CTC_DIAG builds only: ctc_amd_debug_override("wide",
+// "diagN"), N a bit set -- 1: the storer announces rows without waiting for them, 2: lattice rows are dropped, 4: chains alone
+// (nobody computes emissions), 8: the loader stages whatever the ring holds, 16: no gradient pass.
+#ifdef CTC_DIAG
+int g_wide_diag = 0;
+#define CTC_WIDE_DIAG(bits) ((diag & (bits)) != 0)
+#else
+#define CTC_WIDE_DIAG(bits) false
+#endif
 namespace wide {
 
 constexpr int CHUNK = 64;            // frames per emission counter
@@ -150,7 +158,7 @@ __device__ __forceinline__ void chain_loader(const Layout &L, const float *__res
   };
   int vz;
   asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
-  if (diag & 8) {  // (timing diagnostic: whatever the ring holds is declared staged)
+  if (CTC_WIDE_DIAG(8)) {  // (timing diagnostic: whatever the ring holds is declared staged)
     int used = 0;
     for (int k = 0; k < len; ++k) {
       if (k - used >= ER) used = lds_wait_gt(&ctl->e_used, k - ER, ctl);
@@ -207,7 +215,7 @@ __device__ __forceinline__ void chain_storer(const Layout &L, float *__restrict_
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows are in registers: their slots are free
     lds_st(&ctl->o_taken, r0 + n);
-    if (diag & 2) continue;  // (timing diagnostic: rows are dropped)
+    if (CTC_WIDE_DIAG(2)) continue;  // (timing diagnostic: rows are dropped)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {  // (compile-time indices: a runtime row index sent v[][] to scratch memory)
       if (i < n) {
@@ -220,7 +228,7 @@ __device__ __forceinline__ void chain_storer(const Layout &L, float *__restrict_
       }
     }
     if (n == 4) {  // (only the last group can be short; the wavefront drains its stores right after it)
-      if (!(diag & 1)) vmcnt_le<4 * RI + W * GI>();  // everything older than this group's rows and W whole groups has completed
+      if (!CTC_WIDE_DIAG(1)) vmcnt_le<4 * RI + W * GI>();  // everything older than this group's rows and W whole groups has completed
       // rows of groups 0 .. g-W-1 are in memory: 4 (g - W) rows (an announcement every group keeps the instruction count static)
       const int done_rows = g >= W ? 4 * (g - W) : 0;
       if (lane == 0) __hip_atomic_store(sv.rows_done(b, DIR), done_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(256) void wide_kernel(Problem p, Layout L, float *_
         else chain_loader<NL, 1>(L, ebase, len, lane, ering, ctl, diag);
       }
     } else {
-      if (diag & 4) lds_st(&ctl->e_ready, len);  // (timing diagnostic: chains alone, nobody computes emissions)
+      if (CTC_WIDE_DIAG(4)) lds_st(&ctl->e_ready, len);  // (timing diagnostic: chains alone, nobody computes emissions)
       else if (dir == 0) chain_watcher<0>(len, b, sv, ctl);
       else chain_watcher<1>(len, b, sv, ctl);
     }
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(256) void wide_kernel(Problem p, Layout L, float *_
   }
 
   // ---- stream role ----
-  if (diag & 4) return;
+  if (CTC_WIDE_DIAG(4)) return;
   // Every wavefront is a worker of its own (no barrier): worker i of NW takes the rows i, i + NW, ... of the emission pass -- quads
   // of four consecutive frames, utterances walked from both ends towards the middle of THEIR frames: the order in which the chains
   // consume them -- and then of the gradient pass: the valid quads in the reverse order, middle outwards, the order in which alpha
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(256) void wide_kernel(Problem p, Layout L, float *_
       if (lane == 0 && pend != nullptr) __hip_atomic_fetch_add(pend, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       pend = sv.cnt(b) + t / CHUNK;
     } else {
-      if (diag & 16) continue;  // (timing diagnostic: no gradient pass)
+      if (CTC_WIDE_DIAG(16)) continue;  // (timing diagnostic: no gradient pass)
       flush();
       const int q = j < nq ? outside_in(nq - 1 - j, nq) : j;
       const int t = 4 * q + (rid & 3);
@@ -504,7 +512,13 @@ static hipError_t launch(const Problem &p, const Layout &L, char *ws, float *los
     long split = t_chain > t_emit ? (long)((t_chain - t_emit) / t_row_all * (double)(n_stream * 4)) : 0;
     if (split > NR) split = NR;
     hipLaunchKernelGGL((wide_kernel<KIND, NL>), dim3((unsigned)(n_chain + n_stream)), dim3(256), 0, st, q, L, emis, alpha, beta, logp,
-                       loss + b0, d_loss ? d_loss + b0 : nullptr, grad + (long)b0 * p.gsb, sync_words, n_chain, (int)split, g_wide_diag);
+                       loss + b0, d_loss ? d_loss + b0 : nullptr, grad + (long)b0 * p.gsb, sync_words, n_chain, (int)split,
+#ifdef CTC_DIAG
+                       g_wide_diag
+#else
+                       0
+#endif
+    );
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
