@@ -1,7 +1,9 @@
-"""The one-launch tier for vocabularies beyond the fused kernels (csrc/ctc_wide.hip, pipeline "wide": emission, chain and
-gradient stages beside each other in one persistent grid, rows handed over through flags; reached through
-ctc_amd_debug_override("pipeline", "wide") -- the default for these shapes is the three-kernel pipeline "v1") against the
-float64 C oracle and against the three kernels.
+"""Checks of the EXPERIMENTAL one-launch tier for vocabularies beyond the fused kernels (csrc/ctc_wide.hip, pipeline "wide":
+emission, chain and gradient stages beside each other in one persistent grid, rows handed over through flags) against the
+float64 C oracle and against the three kernels.  The tier is not part of the product library: build the
+diagnostic library first and point the binding at it --
+    bash scripts/build_wide_variant.sh && CTC_AMD_LIB=scratch/libctc_wide_diag.so python -m pytest tests/tools/wide_checks.py -q
+(not collected by `pytest tests`: the file name does not match test_*.py).
 
 Edge cases the reference tests (tests/test_ctc_losses.py, tests/test_classic_ctc_loss.py): empty label, label longer than the
 frames allow (loss +inf, zero gradient), logit_length 0, ragged lengths; plus what is specific to this kernel: frame counts
@@ -12,6 +14,8 @@ import numpy as np
 import pytest
 import torch
 
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import c_oracle as C
 
 pytestmark = pytest.mark.gpu

@@ -39,7 +39,8 @@
 namespace ctc {
 // Timing diagnostics (results are then meaningless) exist in CTC_DIAG builds only: ctc_amd_debug_override("wide",
 // "diagN"), N a bit set -- 1: the storer announces rows without waiting for them, 2: lattice rows are dropped, 4: chains alone
-// (nobody computes emissions), 8: the loader stages whatever the ring holds, 16: no gradient pass.
+// (nobody computes emissions), 8: the loader stages whatever the ring holds, 16: no gradient pass, 32 / 64: an agent-scope
+// release fence before every emission-counter bump / every announcement of lattice rows (is visibility the problem?).
 #ifdef CTC_DIAG
 int g_wide_diag = 0;
 #define CTC_WIDE_DIAG(bits) ((diag & (bits)) != 0)
@@ -104,15 +105,24 @@ struct ChainCtl { int e_staged, e_used, o_written, o_taken, dead, e_ready, pad[2
 // abort word polled here -- one emission row per memory round trip, 0.9 us per step).
 __device__ __forceinline__ int lds_wait_gt(const int *p, int base, ChainCtl *ctl) {
   int v = lds_ld(p);
-  if (v > base) return v;
-  for (int it = 0; it < WAIT_LIMIT; ++it) {
-    __builtin_amdgcn_s_sleep(1);
-    v = lds_ld(p);
-    if (v > base) return v;
-    if ((it & 63) == 63 && lds_ld(&ctl->dead) != 0) break;
+  if (!(v > base)) {
+    bool ok = false;
+    for (int it = 0; it < WAIT_LIMIT; ++it) {
+      __builtin_amdgcn_s_sleep(1);
+      v = lds_ld(p);
+      if (v > base) { ok = true; break; }
+      if ((it & 63) == 63 && lds_ld(&ctl->dead) != 0) break;
+    }
+    if (!ok) {
+      lds_st(&ctl->dead, 1);  // (the chain wavefront reports it to the abort word when it ends)
+      v = 0x40000000;         // (every later wait of this wavefront passes at once)
+    }
   }
-  lds_st(&ctl->dead, 1);  // (the chain wavefront reports it to the abort word when it ends)
-  return 0x40000000;      // (every later wait of this wavefront passes at once)
+  // compiler barrier: the ring accesses that follow (plain LDS loads / stores) must not move above the counter read -- a relaxed
+  // atomic load orders nothing by itself, and s_sleep is no memory operation to the optimiser (r03 soak: rare wrong rows at
+  // B = 270, four label positions per lane)
+  asm volatile("" ::: "memory");
+  return v;
 }
 
 // 16 bytes written through (sc1), fire and forget: the storer counts its own vector-memory instructions (vmcnt is in issue order)
@@ -228,6 +238,8 @@ __device__ __forceinline__ void chain_storer(const Layout &L, float *__restrict_
       }
     }
     if (n == 4) {  // (only the last group can be short; the wavefront drains its stores right after it)
+      if (CTC_WIDE_DIAG(64)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (diagnostic: a full release before every announcement)
+      if (CTC_WIDE_DIAG(128)) stores_done();                                      // (diagnostic: drain the stores before every announcement)
       if (!CTC_WIDE_DIAG(1)) vmcnt_le<4 * RI + W * GI>();  // everything older than this group's rows and W whole groups has completed
       // rows of groups 0 .. g-W-1 are in memory: 4 (g - W) rows (an announcement every group keeps the instruction count static)
       const int done_rows = g >= W ? 4 * (g - W) : 0;
@@ -459,8 +471,9 @@ __global__ __launch_bounds__(256) void wide_kernel(Problem p, Layout L, float *_
       if (t >= p.T) continue;
       grad_row<KIND, NL, true>(p, L, emis, alpha, beta, d_loss, grad, b, t, lane, bins, qtab, [&](int len) {
         // alpha row t+1 (classic) / t (simplified) and beta row t+1: alpha rows 0..t+1, beta rows t+1..len
-        wait_ge(sv.rows_done(b, 0), t + 2, sv.abort_word());
-        wait_ge(sv.rows_done(b, 1), len - t, sv.abort_word());
+        const int lag = CTC_WIDE_DIAG(32) ? 16 : 0;  // (diagnostic: ask for 16 rows more than needed)
+        wait_ge(sv.rows_done(b, 0), t + 2 + lag, sv.abort_word());
+        wait_ge(sv.rows_done(b, 1), len - t + lag, sv.abort_word());
       });
     }
   }
@@ -511,6 +524,9 @@ static hipError_t launch(const Problem &p, const Layout &L, char *ws, float *los
     const double t_row_all = (double)(n_chain + n_stream) * 4 * 8.0 * q.V / 4.5e12;  // one row per wavefront, all wavefronts busy
     long split = t_chain > t_emit ? (long)((t_chain - t_emit) / t_row_all * (double)(n_stream * 4)) : 0;
     if (split > NR) split = NR;
+#ifdef CTC_DIAG
+    if (g_wide_diag & 256) split = NR;  // (diagnostic: the chain workgroups take no gradient rows)
+#endif
     hipLaunchKernelGGL((wide_kernel<KIND, NL>), dim3((unsigned)(n_chain + n_stream)), dim3(256), 0, st, q, L, emis, alpha, beta, logp,
                        loss + b0, d_loss ? d_loss + b0 : nullptr, grad + (long)b0 * p.gsb, sync_words, n_chain, (int)split,
 #ifdef CTC_DIAG
