@@ -284,3 +284,33 @@ def test_wide_vocabulary_bench_size_within_1e_4():
     assert np.abs(grad.sum(axis=2)).max() < 2e-5
     for b in range(B):
         assert not grad[b, tl[b]:].any()
+
+
+def test_loss_only_call_with_eight_label_positions_per_lane():
+    """A case the r03 soak run found (tests/golden/soak_case_lossonly_u512.npz: T = 47 of 213 frames, 32 labels, V = 3, logits
+    N(0, 3^2): a nearly forced alignment) with a label bound of 512: the linear-domain sweep of the eight-positions-per-lane
+    instantiation returned 125.0331 for a loss of 125.0488 without raising a flag -- harmless in a call with a gradient (the
+    posterior mass check D6 catches it and the utterance is redone), wrong in a loss-only call.  Loss-only calls of that tier run
+    the log-domain kernel now; the public two-call path (forward, then backward) must give the oracle's loss and gradient."""
+    import os
+    import tf_seq2seq_losses_amd as ctc
+    from tf_seq2seq_losses_amd import ops, _lib
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "soak_case_lossonly_u512.npz"))
+    x, ll, tl = d["x"], d["ll"], d["tl"]
+    labels = np.zeros((1, 512), np.int32)
+    labels[:, :64] = d["labels"]
+    rl, rg = C.loss_grad("classic", labels, x, ll, tl, 0)
+    k = ops.KINDS["classic"]
+    p = ops.Prepared(_t(labels), _t(x), _t(ll), _t(tl), 0, U=512)
+    assert _lib.pipeline_name(k, 0, 1, x.shape[1], x.shape[2], 512, True) == "fused6"
+    assert _lib.pipeline_name(k, 0, 1, x.shape[1], x.shape[2], 512, False) == "fused5"
+    assert _lib.pipeline_name(k, 0, 1, x.shape[1], x.shape[2], 256, False) == "fused6"
+    loss_only, ws = ops.loss_forward(k, _lib.WRT_LOGITS, p)
+    grad = ops.grad_resume(k, _lib.WRT_LOGITS, p, ws)
+    loss_one, grad_one = ops.loss_grad(k, _lib.WRT_LOGITS, p, True)
+    assert abs(float(loss_only[0]) - rl[0]) < 1e-5 * rl[0] and abs(float(loss_one[0]) - rl[0]) < 1e-5 * rl[0]
+    assert torch.equal(grad, grad_one) and np.abs(grad.cpu().numpy() - rg).max() < 1e-5
+    xt = _t(x).requires_grad_(True)   # the public functions: label tensor 512 wide, no hint
+    loss = ctc.classic_ctc_loss(_t(labels), xt, _t(ll), _t(tl), 0, max_label_length=512)
+    (g,) = torch.autograd.grad(loss.sum(), xt)
+    assert abs(float(loss.detach()[0]) - rl[0]) < 1e-5 * rl[0] and np.abs(g.cpu().numpy() - rg).max() < 1e-5
