@@ -3,7 +3,7 @@ ctc_amd_hvp, the first utterances of each compared with the Richardson-extrapola
 NumPy oracle's gradient -- 1e-4 of max|Hv| for utterances the fused kernel kept in the linear domain (its flag word) and, since the log-domain rows take
 posteriors and tangents relative to the frame's own mass, also for
 those it redid in the log domain (sharp logits: the float32 log-domain recursion's own accuracy) -- and with the log-domain
-pipeline forced through the override (2e-4).  usage: python tests/tools/soak_hvp.py [seconds]"""
+pipeline forced through the override (2e-4).  usage: python tests/tools/soak_hvp.py [seconds] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -11,7 +11,7 @@ from oracle import ctc_oracle as O
 from tf_seq2seq_losses_amd import _lib, ops
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
-rng = np.random.default_rng(4321)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4321)
 dev = torch.device("cuda:0")
 t0 = time.time(); n = 0; last = t0; worst_pair = 0.0
 worst = {"linear": 0.0, "redone": 0.0}; count = {"linear": 0, "redone": 0}
