@@ -314,3 +314,27 @@ def test_loss_only_call_with_eight_label_positions_per_lane():
     loss = ctc.classic_ctc_loss(_t(labels), xt, _t(ll), _t(tl), 0, max_label_length=512)
     (g,) = torch.autograd.grad(loss.sum(), xt)
     assert abs(float(loss.detach()[0]) - rl[0]) < 1e-5 * rl[0] and np.abs(g.cpu().numpy() - rg).max() < 1e-5
+
+
+def test_mass_lost_at_the_end_of_a_chain_is_flagged():
+    """A case the r03 producer-format soak found (tests/golden/soak_case_endloss_u128.npz: 43 frames for 34 labels, V = 8, logits
+    N(0, 3^2), label bound 128): the beta chain of the linear-domain kernel loses mass in the LAST frames of its range (frames 0..3).
+    The mass check D6 sampled each helper's first frame of a block and missed it -- gradient 4.3e-3 off, unflagged.  It samples the
+    last frame now (a loss anywhere in a block shows there): the utterance is flagged and redone in the log domain."""
+    import os
+    from tf_seq2seq_losses_amd import ops, _lib
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "soak_case_endloss_u128.npz"))
+    x, labels, ll, tl, kind = d["x"], d["labels"], d["ll"], d["tl"], int(d["kind"])
+    kn = "classic" if kind == 0 else "simplified"
+    rl, rg = C.loss_grad(kn, labels, x, ll, tl, 0)
+    p = ops.Prepared(_t(labels), _t(x), _t(ll), _t(tl), 0, U=128)
+    assert ops.pipeline_of(kind, _lib.WRT_LOGITS, p) == "fused6"
+    ws = torch.zeros(_lib.workspace_bytes(_lib.WS_LOSS_GRAD_LOGITS, kind, 1, x.shape[1], x.shape[2], 128), dtype=torch.uint8, device=_dev())
+    loss, grad = ops.loss_grad(kind, _lib.WRT_LOGITS, p, True, workspace=ws)
+    assert int(ops.fused_flags(ws, kind, p)[0]) & 64
+    assert abs(float(loss[0]) - rl[0]) < 1e-5 * rl[0]
+    assert np.abs(grad.cpu().numpy() - rg).max() < 1e-5
+    # the two-call path: the resume call raises the flag and redoes the utterance
+    loss2, ws2 = ops.loss_forward(kind, _lib.WRT_LOGITS, p)
+    grad2 = ops.grad_resume(kind, _lib.WRT_LOGITS, p, ws2)
+    assert abs(float(loss2[0]) - rl[0]) < 1e-4 * rl[0] and np.abs(grad2.cpu().numpy() - rg).max() < 1e-5

@@ -50,7 +50,7 @@ while time.time() - t0 < budget:
         loss, grad = ops.loss_grad_sum(kind, _lib.WRT_LOGITS, p, sum2)
         fin_t = torch.isfinite(loss)
         assert int(sum2[1]) == int(fin_t.sum()) and int(sum2[0]) == int(torch.round(loss[fin_t].double() * 1048576.0).sum()), (B, T, V, U, kind)
-    m = min(B, 6)
+    m = B if B * T * V <= 4_000_000 else min(B, 6)  # (every utterance where the oracle is cheap: rare inputs hide in the tail of a batch)
     rl, rg = C.loss_grad("classic" if kind == 0 else "simplified", labels[:m], x[:m], ll[:m], tl[:m], 0)
     ln, gn = loss[:m].cpu().numpy(), grad[:m].cpu().numpy()
     fin = np.isfinite(rl)
