@@ -81,6 +81,9 @@ constexpr float EMIS_MIN = 7.52316384526264e-37f;  // 2^-120 (D2)
 // utterance, a loss-only call has nothing to check against.  Every such case had a needed emission below 2^-18.9; N(0,1) logits stay
 // above 2^-13 (the 4.5-sigma tail of 129 000 draws).  So a loss-only call hands sharp utterances to the log domain.
 constexpr float EMIS_SOFT = 1.52587890625e-05f;    // 2^-16 (D7)
+// D6: tolerated deviation of a frame's posterior mass from 1.  The gradient of an unflagged utterance is off by about as much, and the
+// bar is 1e-4: with a tolerance of 1e-4 the soak runs measured up to 9.0e-5 on unflagged utterances -- no margin (r03).
+constexpr float MASS_TOL = 3e-5f;
 
 #ifdef CTC_F6_STAMPS
 // diagnostic build: cycles of work / of waiting at the block barriers, per wavefront and phase (thread-private registers)
@@ -1525,7 +1528,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
 #endif
           static_assert(FPH == 3 || FPH == 2, "one four-value reduction");
           const float qall = swap_reduce<4, false>(qb);  // blank posteriors of the FPH frames and one total mass
-          massbad |= !(fabsf(readlane_f(qall, SwapLanes<4>::lane(FPH)) - 1073741824.0f) < 1073741824.0f * 1e-4f);
+          massbad |= !(fabsf(readlane_f(qall, SwapLanes<4>::lane(FPH)) - 1073741824.0f) < 1073741824.0f * MASS_TOL);
           constexpr bool BATCH = !RELOAD && VPL == 1;  // (register budget: FPH more row sets)
           uint4 PU[BATCH ? FPH : 1][VPL];
           if constexpr (BATCH) static_for<0, FPH>([&](auto Q) { S.scatter(qt[decltype(Q)::value], PU[decltype(Q)::value]); });
@@ -1555,7 +1558,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
 #pragma unroll
             for (int jj = 0; jj < NL; ++jj) tot += qt[jj];
             qb = wave_sum_dpp(qb);
-            massbad |= !(fabsf(wave_sum_dpp(tot) - 1073741824.0f) < 1073741824.0f * 1e-4f);
+            massbad |= !(fabsf(wave_sum_dpp(tot) - 1073741824.0f) < 1073741824.0f * MASS_TOL);
             S.grad_row(geo.frame(DIR, g, d), qb, qt, ev, sd.y);
           }
         }
