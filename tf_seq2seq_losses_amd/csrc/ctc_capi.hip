@@ -150,12 +150,9 @@ static const char *select_pipeline(const ctc::Problem &p, const ctc::Layout &L, 
   // (the parity tests run all of them); nothing here reads the environment.
   const int forced = ctc::g_force_pipeline;
   if (forced == 1) return "v1";
-  // loss only (grad == NULL): fused5 / fused6 stop at the meeting point of their two chains.  With eight label positions per lane
-  // (257..512 labels) a loss-only call runs the LOG-domain tier: the linear-domain sweep of that instantiation returned, on a nearly
-  // forced alignment with sharp logits, a loss 1.3e-4 (relative) off without raising any of its flags (r03 soak, seed 777: T = 47,
-  // 32 labels, logits N(0, 3^2)); a call with a gradient catches such an utterance by its posterior mass (D6) and redoes it, a
-  // loss-only call has nothing to check against.  ctc_amd_grad_resume then computes loss and gradient anew (resume_ok below).
-  if (forced == 0 && ctc::fused6_eligible(p, L)) return (!want_grad && !p.resume && L.NL >= 8) ? "fused5" : "fused6";
+  // loss only (grad == NULL): fused5 / fused6 stop at the meeting point of their two chains
+  (void)want_grad;
+  if (forced == 0 && ctc::fused6_eligible(p, L)) return "fused6";
   if ((forced == 0 || forced == 5) && ctc::fused5_eligible(p, L)) return "fused5";
 #ifdef CTC_DIAG
   // "wide" (ctc_wide.hip: the three stages of v1 beside each other in ONE persistent launch, V > 1024, with a gradient):
@@ -446,7 +443,7 @@ int ctc_amd_grad_resume(int kind, int wrt, const void *logits, int logits_dtype,
   // (eligibility is decided on the same alignment bits the launch will see)
   p.align_bits = low_bits(p.logits, grad);
   ctc::Layout L = ctc::make_layout(p.kind, p.B, p.T, p.U, 0);
-  if (!strcmp(select_pipeline(p, L, true), "fused6") && L.NL < 8) p.resume = 1;  // (NL >= 8: the loss-only call ran the log-domain tier)
+  if (!strcmp(select_pipeline(p, L, true), "fused6")) p.resume = 1;
   return loss_grad_impl(p, loss, grad, d_loss, workspace, workspace_bytes, stream);
 }
 
