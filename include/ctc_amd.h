@@ -102,7 +102,7 @@ int ctc_amd_debug_override(const char *key /*host*/, const char *value /*host*/)
 /*
  * Diagnostic (tests/tools/soak.py, the parity tests): byte offset, inside the workspace of a float32 logits call of these
  * shapes (CTC_AMD_WS_LOSS_GRAD_LOGITS layout), of the int32[B] flag words the linear-domain fused kernel leaves -- 0 = the
- * utterance was computed in the linear domain, != 0 = it was redone by the log-domain roles (bits D1..D6).
+ * utterance was computed in the linear domain, != 0 = it was redone by the log-domain roles (bits D1..D7).
  * Returns CTC_AMD_EINVAL when that call would not run the "fused6" pipeline.
  */
 int ctc_amd_debug_flags_offset(int kind, int B, int T, int V, int U, size_t *out_offset /*host*/);
