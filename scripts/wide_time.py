@@ -1,5 +1,6 @@
-"""Diagnostic: the one-launch wide-vocabulary tier (csrc/ctc_wide.hip) against the three-kernel pipeline at several shapes; HIP
-events around runs of calls; prints a markdown table (profiles/r03_wide_time.md).
+"""Diagnostic: the EXPERIMENTAL one-launch wide-vocabulary tier (csrc/ctc_wide.hip, not part of the product library: build the
+diagnostic library with scripts/build_wide_variant.sh and run with CTC_AMD_LIB=scratch/libctc_wide_diag.so) against the three-kernel
+pipeline at several shapes; HIP events around runs of calls; prints a markdown table (profiles/r03_wide_time.md).
 usage: python scripts/wide_time.py [B,T,U,V ...] [diagN ...]   (diagN: timing diagnostics of the wide tier, bit set described in
 ctc_wide.hip; they exist in CTC_DIAG builds only: scripts/build_wide_variant.sh, then CTC_AMD_LIB=scratch/libctc_wide_diag.so)"""
 import os, sys, statistics as st
