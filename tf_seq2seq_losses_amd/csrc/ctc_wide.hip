@@ -495,7 +495,10 @@ static hipError_t launch(const Problem &p, const Layout &L, char *ws, float *los
   }
   const int capacity = per_cu * n_cu;
   // utterances per launch: their chain workgroups (two each) may take at most half of the resident grid
-  const int bmax = capacity >= 4 ? capacity / 4 : 1;
+  // ... and at most ONE chain workgroup per CU: with two on a CU (more than n_cu / 2 utterances in a launch) some of the lattice
+  // rows they hand over arrive wrong (r03 soak; not understood -- tests/tools/wide_race.py: B = 128 clean, B = 160 not)
+  int bmax = capacity >= 4 ? capacity / 4 : 1;
+  if (bmax > n_cu / 2) bmax = n_cu / 2 > 0 ? n_cu / 2 : 1;
   for (int b0 = 0; b0 < p.B; b0 += bmax) {
     Problem q = p;
     q.B = p.B - b0 < bmax ? p.B - b0 : bmax;
