@@ -12,9 +12,7 @@ NAME=$([ "$KIND" = 0 ] && echo classic || echo simplified)
 TAG=$(basename ${F6_OUT:-f6v})
 hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -Iinclude -I$C -DCTC_FUSED_KIND=$KIND -DCTC_FUSED6_NL=$NLV -fno-slp-vectorize -DCTC_DIAG "$@" -c ${F6_SRC:-$C/ctc_fused6.hip} -o scratch/objv/$TAG.o &
 [ -f scratch/objv/capi_diag.o ] && [ scratch/objv/capi_diag.o -nt $C/ctc_capi.hip ] && [ scratch/objv/capi_diag.o -nt $C/ctc_common.h ] || hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -Iinclude -I$C -DCTC_DIAG -c $C/ctc_capi.hip -o scratch/objv/capi_diag.o
-# (a CTC_DIAG ctc_capi.o also refers to the experimental wide tier, which is not a product unit: scripts/build_wide_variant.sh)
-[ -f scratch/objv/wide_diag.o ] && [ scratch/objv/wide_diag.o -nt $C/ctc_wide.hip ] || hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -Iinclude -I$C -DCTC_DIAG -c $C/ctc_wide.hip -o scratch/objv/wide_diag.o
 wait
 OBJS=$(ls $C/_obj/*.o | grep -v "ctc_fused6_${NAME}_nl${NLV}.o" | grep -v "ctc_capi.o" | grep -v "ctc_wide.o")
-hipcc --offload-arch=gfx950 -fPIC -shared $OBJS scratch/objv/capi_diag.o scratch/objv/wide_diag.o scratch/objv/$TAG.o -o ${F6_OUT:-scratch/libctc_f6v.so}
+hipcc --offload-arch=gfx950 -fPIC -shared $OBJS scratch/objv/capi_diag.o scratch/objv/$TAG.o -o ${F6_OUT:-scratch/libctc_f6v.so}
 echo built ${F6_OUT:-scratch/libctc_f6v.so}

@@ -58,9 +58,9 @@ inline hipError_t run_fused6(const Problem &p, const Layout &L, char *ws, float 
   }
   return e;  // (flagged utterances are redone in the log domain inside the same launch: ctc_fused6.hip, end of fused6_kernel)
 }
-#ifdef CTC_DIAG
-// EXPERIMENTAL, diagnostic builds only (scripts/build_wide_variant.sh): vocabularies beyond the fused tiers with the
-// emission, chain and gradient stages beside each other in one persistent launch (ctc_wide.hip).  Not part of the product library:
+#ifdef CTC_WIDE_EXPERIMENT
+// EXPERIMENTAL, parked outside the product tree (experiments/wide/, built by experiments/wide/build_wide_variant.sh): vocabularies beyond the fused tiers with the
+// emission, chain and gradient stages beside each other in one persistent launch (experiments/wide/ctc_wide.hip).  Not part of the product library:
 // at parity with the three kernels at best, and a soak run found isolated stale rows in large batches.
 bool wide_eligible(const Problem &p, const Layout &L);
 hipError_t run_wide(const Problem &p, const Layout &L, char *ws, float *loss, const float *d_loss, float *grad, hipStream_t st);
@@ -70,10 +70,10 @@ hipError_t run_hessian(const Problem &p, const Layout &L, char *ws, const float 
 size_t hvp_extra_bytes(int kind, int B, int T, int V, int U);
 size_t hvp_fused_flags_offset(int kind, int B, int T, int U);
 // diagnostic overrides (ctc_amd_debug_override): process-wide, written only by tests / benchmarks between calls
-int g_force_pipeline = 0;      // 0 = best eligible tier, 1 = v1 (three kernels), 5 = fused5 (log domain) (7 = the experimental wide tier of CTC_DIAG builds)
+int g_force_pipeline = 0;      // 0 = best eligible tier, 1 = v1 (three kernels), 5 = fused5 (log domain) (7 = the parked wide tier, experiments/wide/ builds only)
 int g_force_hessian_slab = 0;  // 1 = the general one-slab-per-wavefront Hessian kernel also for short labels
 int g_force_hvp_v1 = 0;        // 1 = the log-domain Hessian-vector pipeline also where the fused kernel applies
-#ifdef CTC_DIAG
+#ifdef CTC_WIDE_EXPERIMENT
 extern int g_wide_diag;        // timing diagnostics of the wide-vocabulary kernel (ctc_wide.hip; results are then meaningless)
 #endif
 int g_hvp_diag = 0;            // timing diagnostics of the fused kernel (ctc_hvp_fused.hip `mode`; results are then meaningless)
@@ -154,8 +154,8 @@ static const char *select_pipeline(const ctc::Problem &p, const ctc::Layout &L, 
   (void)want_grad;
   if (forced == 0 && ctc::fused6_eligible(p, L)) return "fused6";
   if ((forced == 0 || forced == 5) && ctc::fused5_eligible(p, L)) return "fused5";
-#ifdef CTC_DIAG
-  // "wide" (ctc_wide.hip: the three stages of v1 beside each other in ONE persistent launch, V > 1024, with a gradient):
+#ifdef CTC_WIDE_EXPERIMENT
+  // "wide" (experiments/wide/ctc_wide.hip: the three stages of v1 beside each other in ONE persistent launch, V > 1024, with a gradient):
   // experimental, diagnostic builds only
   if (forced == 7 && want_grad && ctc::wide_eligible(p, L)) return "wide";
 #endif
@@ -173,8 +173,8 @@ int ctc_amd_debug_override(const char *key, const char *value) {
   if (!key || !value) return fail(CTC_AMD_EINVAL, "null key/value");
   if (!strcmp(key, "pipeline")) {
     int f = !strcmp(value, "") ? 0 : !strcmp(value, "v1") ? 1 : !strcmp(value, "fused5") ? 5 : -1;
-#ifdef CTC_DIAG
-    if (!strcmp(value, "wide")) f = 7;  // (experimental tier of diagnostic builds)
+#ifdef CTC_WIDE_EXPERIMENT
+    if (!strcmp(value, "wide")) f = 7;  // (experiments/wide/ only)
 #endif
     if (f < 0) return fail(CTC_AMD_EINVAL, "pipeline override must be \"\", \"v1\" or \"fused5\", got \"%s\"", value);
     ctc::g_force_pipeline = f;
@@ -196,7 +196,7 @@ int ctc_amd_debug_override(const char *key, const char *value) {
     ctc::g_hvp_diag = 0;
     return CTC_AMD_OK;
   }
-#ifdef CTC_DIAG
+#ifdef CTC_WIDE_EXPERIMENT
   if (!strcmp(key, "wide")) {  // timing diagnostics (scripts/wide_time.py): "" or "diag<number 0..511>"
     int v = 0;
     if (strcmp(value, "") && (sscanf(value, "diag%d", &v) != 1 || v < 0 || v > 511)) return fail(CTC_AMD_EINVAL, "wide override must be \"\" or \"diag0\"..\"diag511\", got \"%s\"", value);
@@ -314,7 +314,7 @@ static int loss_grad_impl(ctc::Problem p, float *loss, void *grad, const float *
     }
     return CTC_AMD_OK;
   }
-#ifdef CTC_DIAG
+#ifdef CTC_WIDE_EXPERIMENT
   if (pl[0] == 'w') {
     hipError_t ew = ctc::run_wide(p, L, static_cast<char *>(workspace), loss, d_loss, gradf, st);
     if (ew != hipSuccess) return hip_fail(ew, "wide launch");
