@@ -38,6 +38,11 @@
 #undef CTC_F6_NH12
 #undef CTC_F6_LA
 #undef CTC_F6_HPRIO_B
+#undef CTC_F6_NS_ONLY
+#undef CTC_F6_NO_D7
+#undef CTC_F6_GAP_LIVE
+#undef CTC_F6_PACKED
+#undef CTC_F6_P1SYNC
 #endif
 
 namespace ctc {

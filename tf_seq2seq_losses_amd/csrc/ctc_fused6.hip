@@ -55,6 +55,20 @@ using namespace ctc::fused;
 
 constexpr int DEAD = -(1 << 24);  // exponent of a lane whose mantissas are all zero
 constexpr int GAP = 16;           // a dead lane adopts its upstream neighbour's exponent minus GAP (per adoption level)
+#ifndef CTC_F6_GAP_LIVE
+#define CTC_F6_GAP_LIVE 80
+#endif
+// A lane that HOLDS mass is lifted towards its upstream neighbour only as far as the inflow needs to stay representable: to the
+// neighbour's exponent minus GAP_LIVE (the inflow then arrives with a mantissa of at most 2^(GAP_LIVE + 7)).  Until r04 live lanes
+// were lifted to the neighbour's exponent minus GAP (16) like lanes without mass, which pushed their own values up to 2^-110 of the
+// lane's exponent and into gradual underflow within the next period -- on nearly forced alignments with sharp logits those thin
+// values ARE the posterior mass (the other direction is as steep the other way), and the sweep lost them without a flag:
+// tests/tools/linear_model.py replays tests/golden/soak_case_endloss_u128.npz (beta at t = 14: the state that carries all of the
+// posterior sits 2^-101 below its lane-mate and 2^-130 below the next lane; lifted by 11 bits it decays into the denormals
+// within the period: 3e-5 of the mass gone at t = 14, 4e-3 at t = 4) and shows the mass intact with this rule.  What the larger gap
+// can cost is an OVERFLOW where a steep front crosses two thin live lanes within one period -- which is detected (P or the
+// posterior mass comes out inf / NaN: D1 / D6), never silent.
+constexpr int GAP_LIVE = CTC_F6_GAP_LIVE;
 constexpr int GAP_WIDE = 64;      // ... when ONE level suffices (a lane of 4 or 8 label positions is never crossed within a period):
                                   // neighbouring lanes then differ by 2^100 and more on benign inputs, and lifting a lane to
                                   // 2^-16 of its neighbour pushed its own values towards the float32 underflow (D4)
@@ -80,7 +94,11 @@ constexpr float EMIS_MIN = 7.52316384526264e-37f;  // 2^-120 (D2)
 // WITHOUT tripping D1..D5 (loss off by 1e-4 .. 3e-2 relative): a call with a gradient sees it in the posterior mass (D6) and redoes the
 // utterance, a loss-only call has nothing to check against.  Every such case had a needed emission below 2^-18.9; N(0,1) logits stay
 // above 2^-13 (the 4.5-sigma tail of 129 000 draws).  So a loss-only call hands sharp utterances to the log domain.
+#ifdef CTC_F6_NO_D7  // (diagnostic builds: what do loss-only calls lose without the guard?)
+constexpr float EMIS_SOFT = 0.f;
+#else
 constexpr float EMIS_SOFT = 1.52587890625e-05f;    // 2^-16 (D7)
+#endif
 // D6: tolerated deviation of a frame's posterior mass from 1.  The gradient of an unflagged utterance is off by about as much, and the
 // bar is 1e-4: with a tolerance of 1e-4 the soak runs measured up to 9.0e-5 on unflagged utterances -- no margin (r03).
 constexpr float MASS_TOL = 3e-5f;
@@ -97,6 +115,8 @@ __device__ Stamps *g_stamps_dummy;
 #define F6_STAMP_PHASE2 st_.ph = 1;
 #define F6_BARRIER() do { __builtin_amdgcn_s_waitcnt(0xC07F); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_.work[st_.ph] += t_ - st_.t0; block_barrier_raw(); \
     unsigned long long u_ = __builtin_amdgcn_s_memtime(); st_.wait[st_.ph] += u_ - t_; st_.t0 = u_; } while (0)
+#define F6_WAIT(expr) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_.work[st_.ph] += t_ - st_.t0; expr; \
+    unsigned long long u_ = __builtin_amdgcn_s_memtime(); st_.wait[st_.ph] += u_ - t_; st_.t0 = u_; } while (0)
 #define F6_STAMP_DUMP(wave) do { if ((threadIdx.x & 63) == 0) { unsigned long long *q_ = reinterpret_cast<unsigned long long *>(flag_ws_dbg + p.B) + ((long)b * 16 + (wave)) * 4; \
     q_[0] = st_.work[0]; q_[1] = st_.wait[0]; q_[2] = st_.work[1]; q_[3] = st_.wait[1]; } } while (0)
 #else
@@ -104,6 +124,7 @@ __device__ Stamps *g_stamps_dummy;
 #define F6_STAMP_DECL
 #define F6_STAMP_PHASE2
 #define F6_BARRIER() block_barrier_raw()
+#define F6_WAIT(expr) do { expr; } while (0)
 #define F6_STAMP_DUMP(wave)
 #endif
 __device__ __forceinline__ void block_barrier_raw() {
@@ -115,11 +136,78 @@ __device__ __forceinline__ void block_barrier_raw() {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// Producer / consumer words in LDS instead of a block barrier (phase 1).  With one s_barrier per block every block lasts as long
+// as its slowest wavefront, and the slowest changes from block to block (a late HBM row here, a renormalisation there): r03's
+// stamps showed every wavefront WAITING 45 % of phase 1.  Each stage has a dependent chain of ~1 us per block (load -> reduction
+// -> exponentials -> reduction -> LDS gather; twelve dependent lattice steps), which the barrier lines up end to end instead
+// of letting them overlap.  Now every E-stage worker publishes "my rows of block j are in LDS" in a word of its own, the chain
+// publishes "block j is in my registers", and a wavefront only ever waits for what it really needs; the E rows' three slots let
+// the workers run up to two blocks ahead of the chain.
+//   * LDS operations of one wavefront execute in program order: a progress word written after the rows it announces is
+//     visible after them, and the chain's "consumed" word, written after its row reads were issued, lands after they executed.
+//   * every wait is bounded: a wavefront that gives up raises D8 (the utterance is redone by the log-domain roles, which use
+//     real barriers) and carries on -- nothing can hang.
+// ------------------------------------------------------------------------------------------------
+#ifndef CTC_F6_P1SYNC
+#define CTC_F6_P1SYNC 0
+#endif
+constexpr int D9_RANGE = 512;                   // flag: a nonzero lattice value left the range a lane's exponent can hold (checked renorm)
+constexpr unsigned RANGE_MIN_BITS = 0x0D800000u - 1u;  // bits of 2^-100, minus one: (bits - 1) < this  <=>  0 < value < 2^-100
+__device__ __forceinline__ unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
+constexpr int SYNC_LIMIT = 1 << 16;  // polls (~100 cycles each with the sleep) before a wait gives up
+constexpr int D8_SYNC = 256;         // flag: a producer / consumer wait timed out
+// (the words are addressed as LDS explicitly: through a generic pointer a volatile access becomes a flat load with `s_waitcnt vmcnt(0)`,
+// which would drain every outstanding HBM load of the polling wavefront)
+typedef __attribute__((address_space(3))) volatile int lds_vint;
+__device__ __forceinline__ lds_vint *as_lds(const int *p) { return (lds_vint *)p; }
+// waits until *p >= target (one word, same address in every lane: an LDS broadcast); false on timeout
+__device__ __forceinline__ bool wait_word_ge(const int *p, int target) {
+  lds_vint *q = as_lds(p);
+  for (int n = 0; n < SYNC_LIMIT; ++n) {
+    if (__builtin_amdgcn_readfirstlane(*q) >= target) return true;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+// waits until p[0 .. n-1] are all >= target (lane i reads word min(i, n-1))
+__device__ __forceinline__ bool wait_words_ge(const int *p, int n, int target, int lane) {
+  lds_vint *q = as_lds(p) + (lane < n ? lane : n - 1);
+  for (int it = 0; it < SYNC_LIMIT; ++it) {
+    if (__builtin_amdgcn_ballot_w64(*q < target) == 0) return true;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+// lane 0 stores v at p, the other lanes into a sink of their own (no exec-mask branch around the store)
+__device__ __forceinline__ void publish_word(int *p, float *dump, int lane, int v) {
+  const int *q = (lane == 0) ? p : reinterpret_cast<const int *>(dump) + lane;
+  *as_lds(q) = v;
+}
+
 __device__ __forceinline__ int from_prev_lane_i(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int from_next_lane_i(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x130, 0xf, 0xf, false); }
 __device__ __forceinline__ float ldexp_f(float x, int e) { return __builtin_ldexpf(x, e); }
 __device__ __forceinline__ int frexp_e(float x) { return __builtin_amdgcn_frexp_expf(x); }
 __device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+// Packed float32 pairs (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two label positions per instruction; a wavefront issues one
+// vector instruction per ~8 cycles whatever its width, profiles/r03_issue_rate.txt) for the two-positions-per-lane classic chains --
+// the roles whose time is their own dependent instruction stream.  NOT for the helpers: their E / G stage arithmetic packed the same
+// way (r04: 263 -> 238 instructions per block) made phase 1 two microseconds SLOWER and phase 2 no faster -- a packed operation
+// occupies the SIMD for two passes, and the helpers share their SIMDs' pipes with the chains (profiles/r04_kernel_experiments.md).
+typedef float f2v __attribute__((ext_vector_type(2)));
+#ifndef CTC_F6_PACKED
+#define CTC_F6_PACKED 1
+#endif
+// acc += (x of the upstream neighbour lane) * sc in ONE instruction (v_fmac_f32 with a DPP source; was v_mov_b32_dpp + v_ldexp_f32 +
+// v_add_f32).  The lane without an upstream neighbour (0 for wave_shr, 63 for wave_shl) is left unchanged (bound_ctrl off: the
+// lane is disabled).  `s_nop 1`: a DPP source written by the preceding VALU instruction needs two wait states, and the compiler
+// does not look into inline assembly.
+template <int DIR>
+__device__ __forceinline__ void fmac_from_upstream(float &acc, float x, float sc) {
+  if constexpr (DIR == 0) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(sc));
+  else asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(sc));
+}
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 
@@ -178,6 +266,8 @@ struct Lds {
   float bins[2 * NH][V + 4];
   float dump[NW][64];
   double l2s[NW];           // per worker: sum over its phase-1 frames of log2 sum_k exp(x_k - rowmax)
+  int p1_prog[2][8];        // phase 1: blocks of side s whose E rows worker w has written (its own word)
+  int p1_cons[2];           // phase 1: blocks of side s whose E rows the main chain has read into registers
   int flag;                 // OR of D1..D5 over the wavefronts
   int feasible;             // 1: phase 2 runs
   int lp_int;               // posterior scale: 2^-lp_int * cf = 1 / (P in mantissa units)
@@ -275,13 +365,17 @@ struct RRow {
 };
 template <int KIND, int NL, class LDt>
 __device__ __forceinline__ void read_R(const float *row, int lane, RRow<KIND, NL> &r) {
-  ld_pairs<NL>(row + 2 * lane * NL, r.c, r.o);
+  if constexpr (KIND == 0 && NL == 2 && CTC_F6_PACKED != 0) {  // (c0, c1, o0, o1): both halves are register pairs for the packed products
+    const float4 t = *reinterpret_cast<const float4 *>(row + 4 * lane);
+    r.c[0] = t.x; r.c[1] = t.y; r.o[0] = t.z; r.o[1] = t.w;
+  } else ld_pairs<NL>(row + 2 * lane * NL, r.c, r.o);
   const float2 t = *reinterpret_cast<const float2 *>(row + 2 * LDt::UP);
   r.cx = t.x; r.kx = __float_as_int(t.y);
 }
 template <int KIND, int NL, class LDt>
 __device__ __forceinline__ void write_R(float *row, float *dump, int lane, const float (&c)[NL], const float (&o)[NL], float cx, int kx) {
-  st_pairs<NL>(row + 2 * lane * NL, c, o);
+  if constexpr (KIND == 0 && NL == 2 && CTC_F6_PACKED != 0) *reinterpret_cast<float4 *>(row + 4 * lane) = make_float4(c[0], c[1], o[0], o[1]);
+  else st_pairs<NL>(row + 2 * lane * NL, c, o);
   float *tq = (lane == 0) ? row + 2 * LDt::UP : dump + (lane & 31) * 2;  // lanes > 0 write a sink
   *reinterpret_cast<float2 *>(tq) = make_float2(cx, __int_as_float(kx));
 }
@@ -300,6 +394,9 @@ struct Chain {
   int k, kx, dk;
   bool norep[NL], norep_next[NL];
   int flag;
+  static constexpr bool PACKED = (CTC_F6_PACKED != 0) && KIND == 0 && NL == 2;
+  float nrf[NL];  // PACKED: 1.0 where the repeat rule lets the diagonal pass (norep_next for A, norep for B), else 0.0
+  float sc, scb;  // PACKED: 2^dk as a float (0 below 2^-126: what v_ldexp_f32 would flush), and the same on the boundary lane only
 
   __device__ __forceinline__ void init_labels(const Problem &p, int b, int lane, int ll) {
     const int32_t *lab = p.labels + (long)b * p.label_stride;
@@ -310,10 +407,13 @@ struct Chain {
       const int tk = tok(i);
       norep[j] = (i == 0) || tk != tok(i - 1);
       norep_next[j] = tok(i + 1) != tk;
+      nrf[j] = ((DIR == 0) ? norep_next[j] : norep[j]) ? 1.f : 0.f;
       c[j] = 0.f;
       o[j] = 0.f;
     }
-    cx = 0.f; k = DEAD; kx = DEAD; dk = 0; flag = 0;
+    cx = 0.f; k = DEAD; kx = DEAD; dk = 0; flag = 0; sc = 1.f;
+    scb = (lane == (DIR == 0 ? 0 : 63)) ? 1.f : 0.f;
+    boundary = lane == (DIR == 0 ? 0 : 63);
     relevant = lane * NL <= ll;  // the lane holds a label position that can carry mass (lanes beyond the label stay empty for good)
   }
 
@@ -338,7 +438,30 @@ struct Chain {
   // one lattice step (the recursions of Side::step in ctc_fused_common.h with log-sum-exp -> +, + -> *)
   __device__ __forceinline__ void step(const Emis<NL> &e) {
     const float bl = e.bl;
-    if constexpr (KIND == 0 && DIR == 0) {
+    if constexpr (PACKED && DIR == 0) {
+      // the generic recursion below, two positions per instruction; bit-identical results (x = c + nr o is one rounding like c + o,
+      // the inflow x_up 2^dk is exact, its sum with o one rounding -- as v_ldexp_f32 + v_add_f32 gave)
+      const f2v C = {c[0], c[1]}, O = {o[0], o[1]}, Y = {e.y[0], e.y[1]}, NR = {nrf[0], nrf[1]};
+      const f2v X = __builtin_elementwise_fma(O, NR, C);
+      const f2v M = C + O;
+      float olo = __builtin_fmaf(cx, scb, O.x);    // lane 0: closed(l = 0) flows in (exponent kx, dk = kx - k there)
+      fmac_from_upstream<0>(olo, X.y, sc);
+      f2v OS = {olo, O.y + X.x};
+      OS = Y * OS;
+      const f2v CN = M * bl;
+      o[0] = OS.x; o[1] = OS.y; c[0] = CN.x; c[1] = CN.y;
+      cx *= bl;
+    } else if constexpr (PACKED && DIR == 1) {
+      const f2v C = {c[0], c[1]}, O = {o[0], o[1]}, Y = {e.y[0], e.y[1]}, NR = {nrf[0], nrf[1]};
+      const f2v H = C * bl;
+      const f2v EE = Y * O;
+      const f2v PN = H + EE;
+      const f2v X = __builtin_elementwise_fma(EE, NR, H);
+      cx *= bl;
+      float ohi = __builtin_fmaf(cx, scb, EE.y);   // lane 63: closed(l = UP) flows in
+      fmac_from_upstream<1>(ohi, X.x, sc);
+      o[0] = EE.x + X.y; o[1] = ohi; c[0] = PN.x; c[1] = PN.y;
+    } else if constexpr (KIND == 0 && DIR == 0) {
       float m[NL], x[NL];
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
@@ -391,8 +514,15 @@ struct Chain {
 
   // per-lane renormalisation: k <- exponent of the lane maximum (lanes without mass adopt the upstream exponent - GAP so
   // that what flows in during the next period is representable), cx to its own exponent, dk refreshed
+  // `checked` (wave-uniform; loss-only calls, which have no posterior mass to check -- D6 -- against): D9, the exact form of "the format
+  // lost something".  With needed emissions > 0 (D2) a lattice value that is nonzero stays nonzero, so (a) a mantissa that WAS
+  // nonzero at the previous renormalisation and is zero now has been flushed, and (b) a nonzero mantissa below 2^-RANGE_MIN of its
+  // lane's exponent -- before or after this renormalisation's shift -- is about to lose bits to gradual underflow, or cannot take a
+  // small inflow any more.  Values only decay between two renormalisations unless something larger flows in, so looking here,
+  // every RN frames, misses nothing.  (Until r04 loss-only calls relied on D3 / D4 -- lane maxima only -- and on D7, a sharpness
+  // heuristic that sent every utterance of a trained model to the log domain.)
   template <int LV>
-  __device__ __forceinline__ void renorm() {
+  __device__ __forceinline__ void renorm(bool checked = false) {
     float m = c[0];
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
@@ -409,7 +539,7 @@ struct Chain {
     // serve lanes without mass, which need an exponent before the front reaches them (wave-uniform branch)
     {
       const int nb = (DIR == 0) ? from_prev_lane_i(kn, ex) : from_next_lane_i(kn, ex);
-      kn = imax(kn, nb - (LV == 1 ? GAP_WIDE : GAP));
+      kn = imax(kn, nb - (live ? imax(GAP_LIVE, LV == 1 ? GAP_WIDE : GAP) : (LV == 1 ? GAP_WIDE : GAP)));
     }
     if (__builtin_amdgcn_ballot_w64(!live && relevant) != 0) {
 #pragma unroll
@@ -430,6 +560,23 @@ struct Chain {
     if (live && d < -DOWN_MAX && dbg0 == 0) { dbg0 = cnt; dbg1 = d; dbg2 = fe; }
     mlast = m;
 #endif
+    if (checked) {
+      // min over the lane's NONZERO mantissas, before and after the shift ((bits - 1) as unsigned: zero becomes the largest value),
+      // and the pattern of zeros against the previous renormalisation's
+      unsigned mn = 0xFFFFFFFFu, zeros = 0u;
+      const int dneg = imin(d, 0);
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        mn = umin(mn, __float_as_uint(ldexp_f(c[j], dneg)) - 1u);
+        zeros |= (c[j] == 0.f ? 1u : 0u) << (2 * j);
+        if constexpr (KIND == 0) {
+          mn = umin(mn, __float_as_uint(ldexp_f(o[j], dneg)) - 1u);
+          zeros |= (o[j] == 0.f ? 2u : 0u) << (2 * j);
+        }
+      }
+      flag |= ((mn < RANGE_MIN_BITS) || (zeros & ~zprev) != 0u) ? D9_RANGE : 0;
+      zprev = zeros;
+    }
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       c[j] = ldexp_f(c[j], d);
@@ -439,7 +586,17 @@ struct Chain {
     cx = ldexp_f(cx, kx - ex);
     kx = ex;
     dk = ((DIR == 0) ? from_prev_lane_i(k, kx) : from_next_lane_i(k, kx)) - k;
+    set_scale();
     alive = live;
+  }
+  unsigned zprev = 0xFFFFFFFFu;  // D9: which of the lane's mantissas were zero at the previous renormalisation (everything, at the start)
+  bool boundary = false;
+  // dk as the factor the packed step multiplies by (after every change of dk)
+  __device__ __forceinline__ void set_scale() {
+    if constexpr (PACKED) {
+      sc = (dk < -126) ? 0.f : ldexp_f(1.f, imin(dk, 127));
+      scb = boundary ? sc : 0.f;
+    }
   }
   bool alive = false;  // the lane had mass at its last renormalisation
   int age = 0;         // consecutive renormalisations with mass
@@ -453,6 +610,7 @@ struct Chain {
     int f = 0;
 #pragma unroll
     for (int bit = 4; bit <= 16; bit <<= 1) f |= (__builtin_amdgcn_ballot_w64((flag & bit) != 0) != 0) ? bit : 0;
+    f |= (__builtin_amdgcn_ballot_w64((flag & D9_RANGE) != 0) != 0) ? D9_RANGE : 0;
     return f;
   }
 
@@ -494,6 +652,7 @@ __device__ __forceinline__ void restore(Chain<KIND, NL, DIR> &S, const CkRow<KIN
   for (int j = 0; j < NL; ++j) { S.c[j] = r.c[j]; S.o[j] = r.o[j]; }
   S.cx = r.cx; S.k = r.k; S.kx = r.kx;
   S.dk = ((DIR == 0) ? from_prev_lane_i(S.k, S.kx) : from_next_lane_i(S.k, S.kx)) - S.k;
+  S.set_scale();
   float m = 0.f;
 #pragma unroll
   for (int j = 0; j < NL; ++j) m = fmaxf(m, fmaxf(r.c[j], r.o[j]));
@@ -553,9 +712,10 @@ struct Rows {
   // exp(x - rowmax) of this lane's elements from the recorded statistic mxl = rowmax * log2(e)
   __device__ __forceinline__ void expo(const float4 (&xr)[VPL], float mxl, float4 (&ev)[VPL]) const {
 #pragma unroll
-    for (int q = 0; q < VPL; ++q)
+    for (int q = 0; q < VPL; ++q) {
       ev[q] = make_float4(fexp2(fmaf(xr[q].x, LOG2E, -mxl)), fexp2(fmaf(xr[q].y, LOG2E, -mxl)),
                           fexp2(fmaf(xr[q].z, LOG2E, -mxl)), fexp2(fmaf(xr[q].w, LOG2E, -mxl)));
+    }
   }
   // emission gather through an LDS copy of the exponentiated row (base_loss.py:328-344, 365-371)
   __device__ __forceinline__ void gather(const float4 (&ev)[VPL], Emis<NL> &e) const {
@@ -760,6 +920,8 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL, VPL, XT> &S, Lds<KI
   // conditional store or load in the loop that is zero, every use of the ring drained ALL outstanding loads and the
   // look-ahead bought nothing (phase 1 ran at the latency of one HBM round trip per block).
   float2 *sink = stats_sink + (wave & 7) * 32 + (lane & 31);  // statistics of lanes that hold no frame go here
+  const int widx = (wave < 4) ? NH : (wave - 4) % NH;         // this worker's progress word (helpers 0 .. NH-1, the recompute wavefront NH)
+  bool sync_bad = false;
   auto body = [&](auto R, auto FASTt, int it) __attribute__((always_inline)) {
     constexpr int r = decltype(R)::value;  // = it mod PFD
     constexpr bool FAST = decltype(FASTt)::value;
@@ -768,6 +930,9 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL, VPL, XT> &S, Lds<KI
       const int g = geo.absblock(1, SIDE, j);
       const int nv = FAST ? BLK : geo.nvof(g);
       float(*E)[LD::ES] = lds.E[SIDE][j % 3];
+      if constexpr (CTC_F6_P1SYNC != 0) {  // slot j % 3 is free once the chain has block j - 3 in its registers
+        F6_WAIT(if (j >= 3 && !wait_word_ge(&lds.p1_cons[SIDE], j - 2)) sync_bad = true);
+      }
       float smx = 0.f, ssum = 1.f;  // lane d keeps the statistics of position d of the block (its sum; ONE reciprocal below)
       if (FAST || nv == BLK) {
         if constexpr (NQ > 0) {
@@ -815,8 +980,9 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL, VPL, XT> &S, Lds<KI
       const bool mine = lane >= P0 && lane < P0 + NQ && lane < nv;
       float2 *dst = mine ? stats + geo.frame(SIDE, g, mine ? lane : 0) : sink;  // unconditional store: no branch
       *dst = make_float2(smx, __builtin_amdgcn_rcpf(ssum));  // 1 / sum exp of this lane's frame
+      if constexpr (CTC_F6_P1SYNC != 0) publish_word(&lds.p1_prog[SIDE][widx], dump, lane, j + 1);  // (after the E rows, in order)
     }
-    F6_BARRIER();
+    if constexpr (CTC_F6_P1SYNC == 0) F6_BARRIER();
   };
   // the first PFD blocks through the general body (side B starts with the utterance's last block, the only one that can
   // be partial); then the steady state; then whatever is left of the NB + 1 iterations every wavefront makes
@@ -851,6 +1017,7 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL, VPL, XT> &S, Lds<KI
   for (int j = 0; j < NL; ++j) sharp = sharp || (S.valid[j] && !(zmin[j] >= EMIS_SOFT));
   if (NQ > 0 && nb > 0 && __builtin_amdgcn_ballot_w64(sharp) != 0 && lane == 0) atomicOr(&lds.flag, 128);
   if (lane == 0) lds.l2s[wave] = acc;
+  if (sync_bad && lane == 0) atomicOr(&lds.flag, D8_SYNC);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -893,34 +1060,43 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
   // ================= phase 1: lattice steps, one checkpoint row per block =================
   {
     const int nb = geo.nblocks(1, DIR);
-    for (int it = 0; it <= geo.NB; ++it) {
+    using SPm = P1Split<BLK, NH, NL>;
+    constexpr int NWK = NH + (SPm::count(NH) > 0 ? 1 : 0);  // E-stage workers of a side that hold frames
+    bool sync_bad = false;
+    for (int it = (CTC_F6_P1SYNC != 0 ? 1 : 0); it <= (CTC_F6_P1SYNC != 0 ? nb : geo.NB); ++it) {
       const int j = it - 1;
       if ((CTC_F6_ONLY & 16) && j >= 0 && j < nb) {
         const int g = geo.absblock(1, DIR, j);
         const int nv = geo.nvof(g);
         const float(*E)[LD::ES] = lds.E[DIR][j % 3];
         spill<KIND, NL, DIR>(S, own_rows, own_k, geo.slot(DIR == 0 ? BLK * g : BLK * g + nv), SRS, UP, lane);
+        if constexpr (CTC_F6_P1SYNC != 0) {  // every worker of this side has written its rows of block j
+          F6_WAIT(if (!wait_words_ge(lds.p1_prog[DIR], NWK, j + 1, lane)) sync_bad = true);
+        }
         if (nv == BLK) {
           // the emission rows of the whole block go to registers first: the sequential chain never waits for an LDS round
           // trip (with the read next to its use every frame paid one, ~100 of its ~190 cycles)
           Emis<NL> eb[BLK];
           static_for<0, BLK>([&](auto D) { read_E<NL, LD>(E[decltype(D)::value], lane, eb[decltype(D)::value]); });
+          if constexpr (CTC_F6_P1SYNC != 0) publish_word(&lds.p1_cons[DIR], dump, lane, j + 1);  // (behind the reads, in order)
           static_for<0, BLK>([&](auto D) {
             constexpr int d = decltype(D)::value;
             S.step(eb[d]);
-            if ((d + 1) % RN == 0) S.template renorm<LV>();
+            if ((d + 1) % RN == 0) S.template renorm<LV>(!want_grad);
           });
         } else {
           for (int d = 0; d < nv; ++d) {
             Emis<NL> e;
             read_E<NL, LD>(E[d], lane, e);
             S.step(e);
-            if ((d + 1) % RN == 0 || d == nv - 1) S.template renorm<LV>();
+            if ((d + 1) % RN == 0 || d == nv - 1) S.template renorm<LV>(!want_grad);
           }
+          if constexpr (CTC_F6_P1SYNC != 0) publish_word(&lds.p1_cons[DIR], dump, lane, j + 1);
         }
       }
-      F6_BARRIER();
+      if constexpr (CTC_F6_P1SYNC == 0) F6_BARRIER();
     }
+    if (sync_bad && lane == 0) atomicOr(&lds.flag, D8_SYNC);
   }
   spill<KIND, NL, DIR>(S, own_rows, own_k, geo.slot(geo.tm), SRS, UP, lane);  // alpha[tm] / beta[tm]: the meeting row
 #ifdef CTC_F6_DEBUG
@@ -966,7 +1142,13 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
     double sl2 = 0.0;
     for (int w = 2; w < LD::NW; ++w) sl2 += lds.l2s[w];
     // D3 / D4 (bits 4, 8, 16) and D7 (128) send a loss-only call to the log-domain kernel; with a gradient the mass check D6 decides
-    const int fl = (lds.flag & (want_grad ? 3 : (31 | 128))) | (okP ? 0 : 1);
+    // a loss-only call has no posterior mass to check (D6): it honours the exact range check D9 of its renormalisations instead
+    // (until r04: the lane-maximum signs D3 / D4 and the sharpness heuristic D7, which are still recorded in the word for diagnostics)
+#ifdef CTC_F6_OLD_LOSSONLY_MASK
+    const int fl = (lds.flag & (want_grad ? (3 | D8_SYNC) : (31 | 128 | D8_SYNC))) | (okP ? 0 : 1);
+#else
+    const int fl = (lds.flag & (want_grad ? (3 | D8_SYNC) : (3 | D8_SYNC | D9_RANGE))) | (okP ? 0 : 1);
+#endif
     if (lane == 0) {
       const double dlogp = (double)flog2(s) + (double)EX - sl2;
       logp_ws[b] = okP ? dlogp : -INFINITY;
@@ -1020,7 +1202,8 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
         // products with it ("shifted" parts) are scaled here, with their own scale KS; the others ("aligned") stay raw and
         // the helper multiplies them by the lane's scale KL (lds.kl), off the sequential chain.
         // S row entry per lane (in place of the R row, a region of 2 NL floats):
-        //   NL >= 2: [aligned blank part (raw), token parts[NL] (raw; simplified: the shifted slot scaled), shifted blank part (scaled)]
+        //   NL > 2 : [aligned blank part (raw), token parts[NL] (raw; simplified: the shifted slot scaled), shifted blank part (scaled)]
+        //   NL = 2 : [token parts[2], aligned blank part, shifted blank part]
         //   NL = 1 : [token part, shifted blank part]
         // the carrier lane's shifted blank part also holds the posterior of the boundary state (scaled with its own K0).
         float(*KLr)[64] = lds.kl[DIR][j % 3];
@@ -1047,19 +1230,32 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
             P0 = ldexp_f(1.f, imin(imax(kc - KK_MAX, 0), KK_MAX2 - KK_MAX));
           }
         };
-        auto one = [&](int d, int qd, bool ren, const Emis<NL> &e, const RRow<KIND, NL> &r, int kRq) __attribute__((always_inline)) {
-          if (qd != q) {  // new exponent group of the rows (the boundary exponent r.kx is constant inside a group as well)
-            q = qd; kR = kRq;
-            ks = (DIR == 0) ? from_next_lane_i(kR, r.kx) : from_prev_lane_i(kR, r.kx);
-            dirty = true;
+        auto one = [&](auto FASTt, int d, int qd, bool ren, const Emis<NL> &e, const RRow<KIND, NL> &r, int kRq) __attribute__((always_inline)) {
+          constexpr bool FASTF = decltype(FASTt)::value;  // (fast_from below: the scales are opened there)
+          if constexpr (!FASTF) {
+            if (qd != q) {  // new exponent group of the rows (the boundary exponent r.kx is constant inside a group as well)
+              q = qd; kR = kRq;
+              ks = (DIR == 0) ? from_next_lane_i(kR, r.kx) : from_prev_lane_i(kR, r.kx);
+              dirty = true;
+            }
+            if (dirty) { setK(); dirty = false; }  // (also: this chain renormalised after the previous frame)
           }
-          if (dirty) { setK(); dirty = false; }  // (also: this chain renormalised after the previous frame)
           // the value one label position over: from the next lane for A (needs l = i+1 of a row that holds l = i), from the
           // previous lane for B; and the row's state at this chain's boundary position (l = 0 for A, l = UP for B)
           const float rs = (DIR == 0) ? from_next_lane(r.c[0], r.cx) : from_prev_lane(r.c[NL - 1], r.cx);
           const float r0 = (DIR == 0) ? r.c[0] : r.c[NL - 1];  // (meaningful on the carrier lane only)
           float qal = 0.f, tok[NL], qsh, p0;
-          if constexpr (KIND == 0) {
+          if constexpr (FASTF) {
+            // full block of a packed chain, scales within 2^KK_MAX (fast_from below checks that where the scales change): the products
+            // of the generic branch below without the two-factor form, the token parts as one packed multiply, no branch
+            if constexpr (DIR == 0) S.step(e);
+            const f2v SO = {S.o[0], S.o[1]}, RO = {r.o[0], r.o[1]};
+            const f2v TK = SO * RO;
+            if constexpr (DIR == 0) { qal = S.c[0] * r.c[1]; qsh = (S.c[1] * rs) * KS; }
+            else { qal = S.c[1] * r.c[0]; qsh = (S.c[0] * rs) * KS; }
+            p0 = S.cx * r0;
+            tok[0] = TK.x; tok[1] = TK.y;
+          } else if constexpr (KIND == 0) {
             if constexpr (DIR == 0) S.step(e);  // A: posterior of frame t from alpha[t+1], beta[t+1]
             // (A renormalises after the products below; its exponent is still the one the scales were built from.  A mantissa
             // product may underflow -- by then it is below 2^-16 units after scaling -- but never overflows)
@@ -1130,7 +1326,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
           qsh = __builtin_fmaf(p0, K0, qsh);  // the boundary state rides in the carrier lane's scaled part
           float *srow = RR[d] + 2 * lane * NL;
           if constexpr (NL == 1) *reinterpret_cast<float2 *>(srow) = make_float2(tok[0], qsh);
-          else if constexpr (NL == 2) *reinterpret_cast<float4 *>(srow) = make_float4(qal, tok[0], tok[1], qsh);
+          else if constexpr (NL == 2) *reinterpret_cast<float4 *>(srow) = make_float4(tok[0], tok[1], qal, qsh);  // (token pair first: an aligned register pair)
           else {  // NL + 2 values: [qal, tok[NL], qsh] as 16-byte pieces and one 8-byte tail
             float sv[NL + 2];
             sv[0] = qal; sv[NL + 1] = qsh;
@@ -1144,7 +1340,58 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
           if constexpr (!(KIND == 0 && DIR == 0)) S.step(e);
           if (ren) { S.template renorm<LV>(); dirty = true; }
         };
-        if (nv == BLK) {
+        // the frames d0 .. nv-1 one by one, everything read where it is used (partial blocks; the tail of a full block of a packed
+        // chain from the segment on in which some lane's scale exceeds 2^KK_MAX)
+        auto generic_from = [&](int d0) __attribute__((always_inline)) {
+          for (int d = d0; d < nv; ++d) {
+            Emis<NL> e;
+            read_E<NL, LD>(E[d], lane, e);
+            RRow<KIND, NL> r;
+            read_R<KIND, NL, LD>(RR[d], lane, r);
+            const int qd = grp(d);
+            one(std::false_type{}, d, qd, (d + 1 + ren_shift<KIND, DIR>()) % RN == 0 || d == nv - 1, e, r, KG[qd][lane]);
+          }
+        };
+        if constexpr (Chain<KIND, NL, DIR>::PACKED) {
+          // Full blocks of the packed chains: straight-line code, NO branch per frame (the per-frame test of `wide` merged two
+          // versions of every frame: five register copies and five scalar instructions per frame on the wavefront whose
+          // instruction count bounds phase 2).  The scales change at positions known at compile time (segment starts); only there
+          // is `wide` tested, and if it is set the rest of the block goes through generic_from, which knows the two-factor form.
+          int dstart = 0;
+          if (nv == BLK) {
+            constexpr int PR = 3;
+            Emis<NL> eb[BLK];
+            RRow<KIND, NL> rb[BLK];
+            int kq[CD::NG];
+            static_for<0, CD::NG>([&](auto Q) { kq[decltype(Q)::value] = KG[decltype(Q)::value][lane]; });
+            static_for<0, PR>([&](auto D) { read_R<KIND, NL, LD>(RR[decltype(D)::value], lane, rb[decltype(D)::value]); });
+            static_for<0, BLK>([&](auto D) { read_E<NL, LD>(E[decltype(D)::value], lane, eb[decltype(D)::value]); });
+            auto fast_from = [&](auto self, auto Dc) __attribute__((always_inline)) -> int {
+              constexpr int d = decltype(Dc)::value;
+              if constexpr (d >= BLK) return BLK;
+              else {
+                constexpr int sA = (KIND == 0 && DIR == 1) ? BLK - d : BLK - 1 - d;
+                constexpr int qd = (sA > 0 ? sA - 1 : 0) / RN;
+                constexpr int sP = (KIND == 0 && DIR == 1) ? BLK - (d - 1) : BLK - 1 - (d - 1);
+                constexpr int qp = (d == 0) ? -1 : (sP > 0 ? sP - 1 : 0) / RN;
+                constexpr bool renp = d > 0 && (d + ren_shift<KIND, DIR>()) % RN == 0;  // this chain renormalised after frame d - 1
+                if constexpr (d + PR < BLK) read_R<KIND, NL, LD>(RR[d + PR], lane, rb[d + PR]);
+                if constexpr (qd != qp || renp) {  // a segment opens here
+                  if constexpr (qd != qp) {
+                    q = qd; kR = kq[qd];
+                    ks = (DIR == 0) ? from_next_lane_i(kR, rb[d].kx) : from_prev_lane_i(kR, rb[d].kx);
+                  }
+                  setK();
+                  if (__builtin_expect(wide, 0)) { --seg; q = -1; return d; }  // (generic_from opens this segment again)
+                }
+                one(std::true_type{}, d, qd, (d + 1 + ren_shift<KIND, DIR>()) % RN == 0, eb[d], rb[d], kq[qd]);
+                return self(self, std::integral_constant<int, d + 1>{});
+              }
+            };
+            dstart = fast_from(fast_from, std::integral_constant<int, 0>{});
+          }
+          if (__builtin_expect(dstart < nv, 0)) generic_from(dstart);
+        } else if (nv == BLK) {
           // emission rows of the whole block and the exponent groups up front, R rows PR frames ahead of their use
           constexpr int PR = 3;
           Emis<NL> eb[BLK];
@@ -1158,17 +1405,10 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
             if constexpr (d + PR < BLK) read_R<KIND, NL, LD>(RR[d + PR], lane, rb[d + PR]);
             constexpr int s = (KIND == 0 && DIR == 1) ? BLK - d : BLK - 1 - d;
             constexpr int qd = (s > 0 ? s - 1 : 0) / RN;
-            one(d, qd, (d + 1 + ren_shift<KIND, DIR>()) % RN == 0, eb[d], rb[d], kq[qd]);
+            one(std::false_type{}, d, qd, (d + 1 + ren_shift<KIND, DIR>()) % RN == 0, eb[d], rb[d], kq[qd]);
           });
         } else {
-          for (int d = 0; d < nv; ++d) {
-            Emis<NL> e;
-            read_E<NL, LD>(E[d], lane, e);
-            RRow<KIND, NL> r;
-            read_R<KIND, NL, LD>(RR[d], lane, r);
-            const int qd = grp(d);
-            one(d, qd, (d + 1 + ren_shift<KIND, DIR>()) % RN == 0 || d == nv - 1, e, r, KG[qd][lane]);
-          }
+          generic_from(0);
         }
       }
       F6_BARRIER();
@@ -1485,7 +1725,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
           constexpr int JS = (KIND == 1) ? (DIR == 0 ? NL - 1 : 0) : -1;  // simplified: the slot whose token part is already scaled
           float qal = 0.f, qsh;
           if constexpr (NL == 1) { const float2 t = *reinterpret_cast<const float2 *>(srow); qt[0] = t.x; qsh = t.y; }
-          else if constexpr (NL == 2) { const float4 t = *reinterpret_cast<const float4 *>(srow); qal = t.x; qt[0] = t.y; qt[1] = t.z; qsh = t.w; }
+          else if constexpr (NL == 2) { const float4 t = *reinterpret_cast<const float4 *>(srow); qt[0] = t.x; qt[1] = t.y; qal = t.z; qsh = t.w; }
           else {
             float sv[NL + 2];
 #pragma unroll
@@ -1623,6 +1863,9 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused6_kernel(Problem p, La
   geo.init(clampi(p.logit_length[b], 0, p.T));
   if (threadIdx.x == 0) {
     lds.flag = 0; lds.feasible = 0; lds.lossval = INFINITY; lds.added = 0;
+    lds.p1_cons[0] = 0; lds.p1_cons[1] = 0;
+#pragma unroll
+    for (int w_ = 0; w_ < 8; ++w_) { lds.p1_prog[0][w_] = 0; lds.p1_prog[1][w_] = 0; }
     if (p.resume) {  // the loss-only call left the outcome of the meeting point in the workspace
       const int f = flag_ws[b];
       const int2 m = meet_ws[b];
@@ -1680,6 +1923,12 @@ static hipError_t launch6(const Problem &p, const Layout &L, float *a, float *b,
   const bool al16 = (p.align_bits & 15) == 0;  // 16-byte row accesses need aligned base pointers as well as strides
   const bool plain = al16 && p.xdtype == 0 && p.V == 256 * VPL && p.xst == p.V && p.gst == p.V;
   const dim3 grid(p.B), block(64 * (4 + 2 * NH));
+#ifdef CTC_F6_NS_ONLY  // experiment builds (scripts/build_f6_variant.sh): the plain-format instantiation only -- a minute instead of seven
+  if (!plain) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((fused6::fused6_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 0>), grid, block, 0, st, p, L, a, b, kexp, lp, stats, sink, loss,
+                     d_loss, grad, flags, meet, perm);
+  return hipGetLastError();
+#else
   if (plain)
     hipLaunchKernelGGL((fused6::fused6_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 0>), grid, block, 0, st, p, L, a, b, kexp, lp, stats, sink, loss,
                        d_loss, grad, flags, meet, perm);
@@ -1693,6 +1942,7 @@ static hipError_t launch6(const Problem &p, const Layout &L, float *a, float *b,
     hipLaunchKernelGGL((fused6::fused6_kernel<CTC_FUSED_KIND, NL, NH, BLK, VPL, 2>), grid, block, 0, st, p, L, a, b, kexp, lp, stats, sink, loss,
                        d_loss, grad, flags, meet, perm);
   return hipGetLastError();
+#endif
 }
 
 // One translation unit per (lattice kind, label positions per lane): -DCTC_FUSED_KIND=0|1 -DCTC_FUSED6_NL=1|2|4.
@@ -1727,7 +1977,10 @@ hipError_t CTC_F6_ENTRY(const Problem &p, const Layout &L, char *ws, float *loss
     if (e != hipSuccess) return e;
     perm = reinterpret_cast<const int *>(ws + L.off_perm);
   }
-#if CTC_FUSED6_NL == 8
+#if defined(CTC_F6_NS_ONLY)
+  if (p.V > 256) return hipErrorInvalidValue;
+  return launch6<CTC_FUSED6_NL, CTC_F6_NH12, 12, 1>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st);
+#elif CTC_FUSED6_NL == 8
   return p.V <= 256 ? launch6<8, 1, 3, 1>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st)
                     : launch6<8, 1, 3, 2>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st);
 #elif CTC_FUSED6_NL == 4
