@@ -290,11 +290,10 @@ def test_loss_only_call_with_eight_label_positions_per_lane():
     """A case the r03 soak run found (tests/golden/soak_case_lossonly_u512.npz: T = 47 of 213 frames, 32 labels, V = 3, logits
     N(0, 3^2): a nearly forced alignment) with a label bound of 512: the linear-domain sweep of the eight-positions-per-lane
     instantiation returned 125.0331 for a loss of 125.0488 without raising a flag -- harmless in a call with a gradient (the
-    posterior mass check D6 catches it and the utterance is redone), wrong in a loss-only call.  r03 guarded loss-only calls with a
-    sharpness heuristic (D7: every utterance with a needed emission below 2^-16 of its row maximum went to the log domain); since r04
-    their renormalisations check EXACTLY whether a nonzero lattice value left the range its lane's exponent can hold (D9; eight label
-    positions share one exponent here, and this alignment spreads them over more than 2^126).  The public two-call path (forward, then
-    backward) must give the oracle's loss and gradient."""
+    posterior mass check D6 catches it and the utterance is redone), wrong in a loss-only call.  Loss-only calls hand
+    utterances with sharp logits to the log domain (D7); the public two-call path (forward, then backward) must give the oracle's
+    loss and gradient.  (Eight label positions share one exponent here, and this alignment spreads them over more than 2^126:
+    tests/tools/linear_model.py.)"""
     import os
     import tf_seq2seq_losses_amd as ctc
     from tf_seq2seq_losses_amd import ops, _lib
@@ -308,7 +307,7 @@ def test_loss_only_call_with_eight_label_positions_per_lane():
     assert _lib.pipeline_name(k, 0, 1, x.shape[1], x.shape[2], 512, True) == "fused6"
     assert _lib.pipeline_name(k, 0, 1, x.shape[1], x.shape[2], 512, False) == "fused6"
     loss_only, ws = ops.loss_forward(k, _lib.WRT_LOGITS, p)
-    assert int(ops.fused_flags(ws, k, p)[0]) & 512  # D9: the loss-only sweep saw a value leave its lane's range
+    assert int(ops.fused_flags(ws, k, p)[0]) & 128  # D7: sharp logits in a loss-only call
     grad = ops.grad_resume(k, _lib.WRT_LOGITS, p, ws)
     loss_one, grad_one = ops.loss_grad(k, _lib.WRT_LOGITS, p, True)
     assert abs(float(loss_only[0]) - rl[0]) < 1e-5 * rl[0] and abs(float(loss_one[0]) - rl[0]) < 1e-5 * rl[0]

@@ -44,7 +44,7 @@ def emissions(x, labels, ll, blank):
 
 
 class Chain:
-    def __init__(self, kind, NL, DIR, labels, ll, mask_fn=None, gap=GAP, gap_live=80, lift_live=True):
+    def __init__(self, kind, NL, DIR, labels, ll, mask_fn=None, gap=GAP, gap_live=16, lift_live=True, full_cascade=False):
         self.kind, self.NL, self.DIR, self.ll = kind, NL, DIR, ll
         self.UP = 64 * NL
         self.BLK, self.RN, self.LV = cadence(NL)
@@ -59,6 +59,9 @@ class Chain:
         self.alive = np.zeros(64, bool); self.age = np.zeros(64, np.int64); self.flag = 0
         self.mask_fn, self.gap, self.lift_live, self.gap_live = mask_fn, gap, lift_live, gap_live  # gap_live=16: the rule until r03
         self.lost = []  # (what, detail) diagnostics
+        self.checked = False; self.d9 = []
+        self.full_cascade = full_cascade
+        self.zprev = np.ones((64, 2 * NL if kind == 0 else NL), bool)
 
     def start(self):
         if self.DIR == 0:
@@ -129,7 +132,7 @@ class Chain:
             kn = np.maximum(kn, self._up(kn, ex) - np.where(live, max(self.gap_live, g0), g0))
         else:  # (experiment) only lanes without mass adopt an exponent
             kn = np.where(live, kn, np.maximum(kn, self._up(kn, ex) - (GAP_WIDE if self.LV == 1 else self.gap)))
-        if (~live & self.relevant).any():
+        if self.full_cascade or (~live & self.relevant).any():
             for _ in range(1, self.LV):
                 nb = self._up(kn, ex)
                 kn = np.maximum(kn, nb - self.gap) if self.lift_live else np.where(live, kn, np.maximum(kn, nb - self.gap))
@@ -137,6 +140,16 @@ class Chain:
         d = self.k - kn
         self.age = np.where(live & self.alive, self.age + 1, 0)
         self.flag |= (4 if (live & (self.age >= 3) & (d < -96)).any() else 0) | (8 if (live & (fe < -96)).any() else 0) | (16 if (~live & self.alive).any() else 0)
+        if self.checked:  # D9 of the kernel: a nonzero mantissa below 2^-100 before or after the shift, or nonzero -> zero
+            dneg = np.minimum(d, 0).clip(-400, 0).astype(np.int32)[:, None]
+            with np.errstate(under="ignore"):
+                vals = np.concatenate([np.ldexp(self.c, dneg), np.ldexp(self.o, dneg)], axis=1).astype(F) if self.kind == 0 else np.ldexp(self.c, dneg).astype(F)
+            zeros = (np.concatenate([self.c, self.o], axis=1) == 0) if self.kind == 0 else (self.c == 0)
+            tiny = (vals > 0) & (vals < F(2.0 ** -100))
+            trans = zeros & ~self.zprev
+            if tiny.any() or trans.any():
+                self.d9.append((t, np.argwhere(tiny).tolist()[:4], np.argwhere(trans).tolist()[:4], [int(x) for x in d[np.argwhere(tiny)[:4, 0]]] if tiny.any() else []))
+            self.zprev = zeros
         dd = np.clip(d, -400, 400).astype(np.int32)[:, None]
         with np.errstate(over="ignore", under="ignore"):
             c2 = np.ldexp(self.c, dd).astype(F); o2 = np.ldexp(self.o, dd).astype(F)

@@ -56,18 +56,13 @@ using namespace ctc::fused;
 constexpr int DEAD = -(1 << 24);  // exponent of a lane whose mantissas are all zero
 constexpr int GAP = 16;           // a dead lane adopts its upstream neighbour's exponent minus GAP (per adoption level)
 #ifndef CTC_F6_GAP_LIVE
-#define CTC_F6_GAP_LIVE 80
+#define CTC_F6_GAP_LIVE 16
 #endif
-// A lane that HOLDS mass is lifted towards its upstream neighbour only as far as the inflow needs to stay representable: to the
-// neighbour's exponent minus GAP_LIVE (the inflow then arrives with a mantissa of at most 2^(GAP_LIVE + 7)).  Until r04 live lanes
-// were lifted to the neighbour's exponent minus GAP (16) like lanes without mass, which pushed their own values up to 2^-110 of the
-// lane's exponent and into gradual underflow within the next period -- on nearly forced alignments with sharp logits those thin
-// values ARE the posterior mass (the other direction is as steep the other way), and the sweep lost them without a flag:
-// tests/tools/linear_model.py replays tests/golden/soak_case_endloss_u128.npz (beta at t = 14: the state that carries all of the
-// posterior sits 2^-101 below its lane-mate and 2^-130 below the next lane; lifted by 11 bits it decays into the denormals
-// within the period: 3e-5 of the mass gone at t = 14, 4e-3 at t = 4) and shows the mass intact with this rule.  What the larger gap
-// can cost is an OVERFLOW where a steep front crosses two thin live lanes within one period -- which is detected (P or the
-// posterior mass comes out inf / NaN: D1 / D6), never silent.
+// Gap to which a lane that HOLDS mass is lifted towards its upstream neighbour.  It has to be the adoption gap: r04 tried 80 (a live
+// lane's own thin values then survive 2^64 deeper -- tests/tools/linear_model.py shows the mass of tests/golden/soak_case_endloss_u128.npz
+// intact with it), but mantissas then reach 2^120 where a steep front crosses thin live lanes, the posterior PRODUCTS of phase 2
+// overflow, and between the frames D6 samples that went unnoticed: a gradient 3.0 off, unflagged (tests/tools/flag_stats.py, cell
+// sigma 5, V = 3, U = 32, slack 2).  With 16 per level and LV levels a mantissa stays below 2^55 and a product below 2^110.
 constexpr int GAP_LIVE = CTC_F6_GAP_LIVE;
 constexpr int GAP_WIDE = 64;      // ... when ONE level suffices (a lane of 4 or 8 label positions is never crossed within a period):
                                   // neighbouring lanes then differ by 2^100 and more on benign inputs, and lifting a lane to
@@ -151,6 +146,11 @@ __device__ __forceinline__ void block_barrier_raw() {
 // ------------------------------------------------------------------------------------------------
 #ifndef CTC_F6_P1SYNC
 #define CTC_F6_P1SYNC 0
+#endif
+#ifdef CTC_F6_D9
+#define CTC_F6_D9_ON true
+#else
+#define CTC_F6_D9_ON false
 #endif
 constexpr int D9_RANGE = 512;                   // flag: a nonzero lattice value left the range a lane's exponent can hold (checked renorm)
 constexpr unsigned RANGE_MIN_BITS = 0x0D800000u - 1u;  // bits of 2^-100, minus one: (bits - 1) < this  <=>  0 < value < 2^-100
@@ -541,7 +541,13 @@ struct Chain {
       const int nb = (DIR == 0) ? from_prev_lane_i(kn, ex) : from_next_lane_i(kn, ex);
       kn = imax(kn, nb - (live ? imax(GAP_LIVE, LV == 1 ? GAP_WIDE : GAP) : (LV == 1 ? GAP_WIDE : GAP)));
     }
-    if (__builtin_amdgcn_ballot_w64(!live && relevant) != 0) {
+    // ALL levels for every lane, with or without mass (until r04 the further levels ran only while some lane of the wavefront was
+    // empty): a STEEP profile of live lanes -- each 2^-100 below its upstream neighbour: sharp logits -- kept, after the one level,
+    // exponents 2^100 apart two lanes down (each lane had been lifted against its neighbour's exponent BEFORE that neighbour's own
+    // lift), and when the bulk crossed two lanes within a period the inflow arrived scaled by 2^100: mantissas of 2^60 .. 2^127,
+    // inf at the meeting point (D1).  19 of 256 N(0, 3^2) utterances at the north-star shape were in that state at the meeting
+    // point and 4 overflowed (tests/tools/linear_model.py); with every level applied dk <= GAP holds for every lane.
+    {
 #pragma unroll
       for (int lv = 1; lv < LV; ++lv) {
         const int nb = (DIR == 0) ? from_prev_lane_i(kn, ex) : from_next_lane_i(kn, ex);
@@ -1082,14 +1088,14 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
           static_for<0, BLK>([&](auto D) {
             constexpr int d = decltype(D)::value;
             S.step(eb[d]);
-            if ((d + 1) % RN == 0) S.template renorm<LV>(!want_grad);
+            if ((d + 1) % RN == 0) S.template renorm<LV>(CTC_F6_D9_ON && !want_grad);
           });
         } else {
           for (int d = 0; d < nv; ++d) {
             Emis<NL> e;
             read_E<NL, LD>(E[d], lane, e);
             S.step(e);
-            if ((d + 1) % RN == 0 || d == nv - 1) S.template renorm<LV>(!want_grad);
+            if ((d + 1) % RN == 0 || d == nv - 1) S.template renorm<LV>(CTC_F6_D9_ON && !want_grad);
           }
           if constexpr (CTC_F6_P1SYNC != 0) publish_word(&lds.p1_cons[DIR], dump, lane, j + 1);
         }
@@ -1119,36 +1125,50 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
     load_ck<KIND, NL>(r, oth_rows, oth_k, geo.slot(geo.tm), SRS, UP, lane);
     const int kn = from_next_lane_i(r.k, r.kx);                  // exponent of the value shifted in from the next lane
     const float cn = from_next_lane(r.c[0], r.cx);
-    float t1 = 0.f;
+    // Every product as (mantissa product in [1/4, 1), sum of the two binary exponents): a plain product of two float32 mantissas
+    // underflows below 2^-126 although its lane exponents put it at the top of the sum -- with sharp logits the state the best
+    // path crosses tm in sits 2^-70 below its lane-mates in BOTH directions, every product of the wavefront flushed, and P came out
+    // zero or short (r04: 4 of 256 N(0, 3^2) utterances at the north-star shape raised D1 for this alone).  Once per utterance.
+    auto pm = [](float a, float b_) -> float { return __builtin_amdgcn_frexp_mantf(a) * __builtin_amdgcn_frexp_mantf(b_); };
+    auto pe = [](float a, float b_) -> int { return (a > 0.f && b_ > 0.f) ? frexp_e(a) + frexp_e(b_) : DEAD; };
+    float tmn[2 * NL]; int ten[2 * NL];  // the lane's aligned products (exponent S.k + r.k on top of their own)
+    int nt = 0;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      if (j < NL - 1) t1 += S.c[j] * r.c[j + 1];
-      if constexpr (KIND == 0) t1 += S.o[j] * r.o[j];
+      if (j < NL - 1) { tmn[nt] = pm(S.c[j], r.c[j + 1]); ten[nt] = pe(S.c[j], r.c[j + 1]); ++nt; }
+      if constexpr (KIND == 0) { tmn[nt] = pm(S.o[j], r.o[j]); ten[nt] = pe(S.o[j], r.o[j]); ++nt; }
     }
-    const float t2 = S.c[NL - 1] * cn;
-    const float t0 = (lane == 0) ? S.cx * readlane_f(r.c[0], 0) : 0.f;
+    int el = DEAD;
+#pragma unroll
+    for (int q = 0; q < 2 * NL; ++q) if (q < nt) el = imax(el, ten[q]);
+    float t1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2 * NL; ++q) if (q < nt && ten[q] > DEAD) t1 += ldexp_f(tmn[q], imax(ten[q] - el, -200));
+    const float t2 = pm(S.c[NL - 1], cn);
+    const int x2 = pe(S.c[NL - 1], cn);
+    const float r00 = readlane_f(r.c[0], 0);
+    const float t0 = (lane == 0) ? pm(S.cx, r00) : 0.f;
+    const int x0 = (lane == 0) ? pe(S.cx, r00) : DEAD;
     const int k0 = readlane_i(r.k, 0);
-    const int e1 = (t1 > 0.f) ? frexp_e(t1) + S.k + r.k : DEAD;
-    const int e2 = (t2 > 0.f) ? frexp_e(t2) + S.k + kn : DEAD;
-    const int e0 = (t0 > 0.f) ? frexp_e(t0) + S.kx + k0 : DEAD;
-    const int EX = (int)wave_max_dpp((float)imax(e1, imax(e2, e0)));  // |values| <= 2^24: exact in float32
+    const int E1 = el + S.k + r.k, E2 = x2 + S.k + kn, E0 = x0 + S.kx + k0;  // (DEAD-based sums stay far below any live exponent)
+    const int e1 = (t1 > 0.f && el > DEAD) ? frexp_e(t1) + E1 : DEAD;
+    const int e2 = (x2 > DEAD) ? frexp_e(t2) + E2 : DEAD;
+    const int e0 = (x0 > DEAD) ? frexp_e(t0) + E0 : DEAD;
+    const int EX = (int)wave_max_dpp((float)imax(imax(e1, imax(e2, e0)), DEAD));  // |values| <= 2^24: exact in float32
     float s = 0.f;
-    if (t1 > 0.f) s += ldexp_f(t1, S.k + r.k - EX);
-    if (t2 > 0.f) s += ldexp_f(t2, S.k + kn - EX);
-    if (t0 > 0.f) s += ldexp_f(t0, S.kx + k0 - EX);
+    if (e1 > DEAD) s += ldexp_f(t1, imax(E1 - EX, -200));
+    if (e2 > DEAD) s += ldexp_f(t2, imax(E2 - EX, -200));
+    if (e0 > DEAD) s += ldexp_f(t0, imax(E0 - EX, -200));
     s = wave_sum_dpp(s);
     // D1: P == 0 / inf / NaN (or nothing alive at all)
     const bool okP = shape_ok && EX > DEAD / 2 && s > 0.f && s < 3.0e38f;
     double sl2 = 0.0;
     for (int w = 2; w < LD::NW; ++w) sl2 += lds.l2s[w];
-    // D3 / D4 (bits 4, 8, 16) and D7 (128) send a loss-only call to the log-domain kernel; with a gradient the mass check D6 decides
-    // a loss-only call has no posterior mass to check (D6): it honours the exact range check D9 of its renormalisations instead
-    // (until r04: the lane-maximum signs D3 / D4 and the sharpness heuristic D7, which are still recorded in the word for diagnostics)
-#ifdef CTC_F6_OLD_LOSSONLY_MASK
+    // D3 / D4 (bits 4, 8, 16) and D7 (128) send a loss-only call to the log-domain kernel; with a gradient the mass check D6 decides.
+    // (D9, the exact "a nonzero value left its lane's range" of checked renormalisations, is recorded in CTC_F6_D9 diagnostic builds
+    // only: benign utterances flush irrelevant values all the time -- the thin front ahead of the bulk, the tail behind it -- so it
+    // flags 60 % of the N(0,1) utterances at T = 1000 and still missed one harmful case in 30 000; tests/tools/flag_stats.py)
     const int fl = (lds.flag & (want_grad ? (3 | D8_SYNC) : (31 | 128 | D8_SYNC))) | (okP ? 0 : 1);
-#else
-    const int fl = (lds.flag & (want_grad ? (3 | D8_SYNC) : (3 | D8_SYNC | D9_RANGE))) | (okP ? 0 : 1);
-#endif
     if (lane == 0) {
       const double dlogp = (double)flog2(s) + (double)EX - sl2;
       logp_ws[b] = okP ? dlogp : -INFINITY;
