@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CTC_AMD_ABI_VERSION 4
+#define CTC_AMD_ABI_VERSION 5
 
 /* lattice variant */
 #define CTC_AMD_CLASSIC 0    /* classic_ctc_loss.py:33-70   (collapse repeats, then drop blanks)   */
@@ -260,8 +260,30 @@ int ctc_amd_loss_grad_sum(int kind, int wrt,
                           void *workspace, size_t workspace_bytes, void *stream);
 
 /*
- * Second half of a forward -> backward pair: the gradient for a loss that ctc_amd_loss_grad / ctc_amd_loss_grad_ex has just
- * computed with grad == NULL, weighted by d_loss (which a training loop only knows once the backward pass runs).
+ * First half of a forward -> backward pair (ABI v5): the losses alone, for a caller that WILL ask for the gradient of the same
+ * batch with ctc_amd_grad_resume (torch.autograd: forward now, backward once d_loss is known).
+ * Replaces: forward_fn (base_loss.py:140-149) when a backward pass follows.
+ * Same work and same workspace contents as ctc_amd_loss_grad_ex with grad == NULL.  The difference is which utterances the
+ * linear-domain kernel hands to its log-domain roles.  A loss-only call has no posterior mass to check its sweeps against; a
+ * stand-alone one (ctc_amd_loss_grad* with grad == NULL: inference, scoring) therefore sends every utterance that shows one of
+ * the kernel's conservative signs there -- which includes every utterance with logits as sharp as a trained model's (D7).  This
+ * call honours those signs only for BINDING alignments (fewer than 64 frames to spare over what the labels need): the resume
+ * call checks every utterance's posterior mass and redoes what fails, so the gradient is always verified; the loss of a
+ * non-binding utterance is taken from the linear sweeps as it stands (measured: tests/tools/flag_stats.py).
+ * Shapes that do not run the linear-domain fused kernel behave exactly like ctc_amd_loss_grad_ex with grad == NULL.
+ * Workspace: CTC_AMD_WS_LOSS_GRAD (or CTC_AMD_WS_LOSS_GRAD_LOGITS), to be handed to ctc_amd_grad_resume untouched.
+ */
+int ctc_amd_loss_forward(int kind, int wrt,
+                         const void *logits, int logits_dtype, int64_t logits_stride_b, int64_t logits_stride_t,
+                         const int32_t *labels, int label_stride,
+                         const int32_t *label_length, const int32_t *logit_length, int blank_index,
+                         int B, int T, int V, int U,
+                         float *loss,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Second half of a forward -> backward pair: the gradient for a loss that ctc_amd_loss_forward (or ctc_amd_loss_grad /
+ * ctc_amd_loss_grad_ex with grad == NULL) has just computed, weighted by d_loss (which a training loop only knows once the backward pass runs).
  * Replaces: forward_fn.backprop (base_loss.py:150-153) when the forward pass has already run.
  * The loss-only call stops where the alpha and beta chains meet and leaves its checkpoints, the softmax statistics and
  * log P in the workspace; this call runs the remaining half of the same kernel from there (together: one loss+gradient

@@ -311,7 +311,9 @@ def test_loss_only_call_with_eight_label_positions_per_lane():
     grad = ops.grad_resume(k, _lib.WRT_LOGITS, p, ws)
     loss_one, grad_one = ops.loss_grad(k, _lib.WRT_LOGITS, p, True)
     assert abs(float(loss_only[0]) - rl[0]) < 1e-5 * rl[0] and abs(float(loss_one[0]) - rl[0]) < 1e-5 * rl[0]
-    assert torch.equal(grad, grad_one) and np.abs(grad.cpu().numpy() - rg).max() < 1e-5
+    # (until r04 the one-call form flagged this utterance too -- D6 -- and both gradients came from the log-domain roles, bit for
+    # bit; with every adoption level applied to every lane the linear-domain sweeps hold it: both must be the oracle's)
+    assert np.abs(grad.cpu().numpy() - rg).max() < 1e-5 and np.abs(grad_one.cpu().numpy() - rg).max() < 1e-5
     xt = _t(x).requires_grad_(True)   # the public functions: label tensor 512 wide, no hint
     loss = ctc.classic_ctc_loss(_t(labels), xt, _t(ll), _t(tl), 0, max_label_length=512)
     (g,) = torch.autograd.grad(loss.sum(), xt)

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTC_AMD_LIB", os.path.join(_HERE, "libctc_amd.so"))  # override: kernel experiments only
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 CLASSIC, SIMPLIFIED = 0, 1
 WRT_LOGITS, WRT_LOGPROBS = 0, 1
 WS_LOSS_GRAD, WS_ALPHA_BETA, WS_HESSIAN, WS_HVP, WS_LOSS_GRAD_LOGITS = 0, 1, 2, 3, 4
@@ -55,6 +55,10 @@ SIGNATURES = {
                                        _c_int, _c_int, _c_int, _c_int,
                                        _c_void_p, _c_void_p, _c_int, ctypes.c_int64, ctypes.c_int64,
                                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),  # d_loss, sum2, zero_next, ws, bytes, stream
+    "ctc_amd_loss_forward": (_c_int, [_c_int, _c_int, _c_void_p, _c_int, ctypes.c_int64, ctypes.c_int64,
+                                      _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int,
+                                      _c_int, _c_int, _c_int, _c_int,
+                                      _c_void_p, _c_void_p, _c_size_t, _c_void_p]),                     # loss, ws, bytes, stream
     "ctc_amd_grad_resume": (_c_int, [_c_int, _c_int, _c_void_p, _c_int, ctypes.c_int64, ctypes.c_int64,
                                      _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int,
                                      _c_int, _c_int, _c_int, _c_int,

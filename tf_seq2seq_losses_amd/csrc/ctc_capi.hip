@@ -421,6 +421,29 @@ int ctc_amd_loss_grad_sum(int kind, int wrt, const void *logits, int logits_dtyp
   return loss_grad_impl(p, loss, grad, d_loss, workspace, workspace_bytes, stream);
 }
 
+int ctc_amd_loss_forward(int kind, int wrt, const void *logits, int logits_dtype, int64_t logits_stride_b,
+                         int64_t logits_stride_t, const int32_t *labels, int label_stride, const int32_t *label_length,
+                         const int32_t *logit_length, int blank_index, int B, int T, int V, int U, float *loss, void *workspace,
+                         size_t workspace_bytes, void *stream) {
+  int rc = check_common(kind, wrt, static_cast<const float *>(logits), labels, label_stride, label_length, logit_length,
+                        blank_index, B, T, V, U);
+  if (rc) return rc;
+  if (logits_dtype < CTC_AMD_F32 || logits_dtype > CTC_AMD_F16)
+    return fail(CTC_AMD_EINVAL, "dtype must be CTC_AMD_F32, CTC_AMD_BF16 or CTC_AMD_F16 (logits %d)", logits_dtype);
+  if (B == 0) return CTC_AMD_OK;
+  if (logits_stride_t < V || logits_stride_b < V) return fail(CTC_AMD_EINVAL, "strides smaller than a row of V=%d elements", V);
+  ctc::Problem p = make_problem(kind, wrt, static_cast<const float *>(logits), labels, label_stride, label_length, logit_length,
+                                blank_index, B, T, V, U);
+  p.xsb = logits_stride_b; p.xst = logits_stride_t; p.xdtype = logits_dtype;
+  // (no gradient in this half: the pipeline is chosen as for a gradient in the logits' own format, which is what the front ends ask
+  // ctc_amd_grad_resume for)
+  p.gsb = logits_stride_b; p.gst = logits_stride_t; p.gdtype = logits_dtype;
+  // (Problem::resume: 0 = a call of its own, 1 = second half of a pair, 2 = first half of a pair -- the linear-domain kernel then
+  // honours its conservative loss-only signs for binding alignments only, ctc_fused6.hip; other pipelines do not look at it)
+  p.resume = 2;
+  return loss_grad_impl(p, loss, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
 int ctc_amd_grad_resume(int kind, int wrt, const void *logits, int logits_dtype, int64_t logits_stride_b,
                         int64_t logits_stride_t, const int32_t *labels, int label_stride, const int32_t *label_length,
                         const int32_t *logit_length, int blank_index, int B, int T, int V, int U, float *loss, void *grad,

@@ -84,6 +84,7 @@ constexpr int KK_MAX = 90;        // Posterior scale 2^KK_MAX at most in ONE fac
                                   // a wave-uniform branch per frame, taken only while some lane of the wavefront needs it.
 constexpr int KK_MAX2 = 200;      // D5: beyond this even the pre-scaled operand would leave float32
 constexpr float EMIS_MIN = 7.52316384526264e-37f;  // 2^-120 (D2)
+constexpr int BIND_SLACK = 64;    // loss-only calls honour the soft signs D3 / D4 / D7 below this many spare frames (see the meeting point)
 // D7 (loss-only calls): a needed emission below 2^-16 of its row maximum -- "sharp" logits.  The r03 soak runs found utterances with
 // logits N(0, 3^2) on nearly forced alignments (2..15 frames more than labels) whose linear-domain sweeps lose mass that matters later
 // WITHOUT tripping D1..D5 (loss off by 1e-4 .. 3e-2 relative): a call with a gradient sees it in the posterior mass (D6) and redoes the
@@ -611,6 +612,13 @@ struct Chain {
   int cnt = 0, dbg0 = 0, dbg1 = 0, dbg2 = 0;
   float mlast = 0.f;
 #endif
+  // number of label positions 1 .. ll-1 that repeat their predecessor (classic: each costs one more frame); wave-uniform
+  __device__ __forceinline__ int repeats(int ll, int lane) const {
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) n += __builtin_popcountll(__builtin_amdgcn_ballot_w64(!norep[j] && lane * NL + j < ll));
+    return n;
+  }
   // OR of the lanes' flags (wave-uniform)
   __device__ __forceinline__ int flag_or() const {
     int f = 0;
@@ -1057,7 +1065,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
   (void)flag_ws_dbg;
   F6_STAMP_DECL
 
-  if (p.resume) {
+  if (p.resume == 1) {
     // second call of a loss -> gradient pair: this chain continues from its own row at the meeting point
     CkRow<KIND, NL> r;
     load_ck<KIND, NL>(r, own_rows, own_k, geo.slot(geo.tm), SRS, UP, lane);
@@ -1168,7 +1176,17 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
     // (D9, the exact "a nonzero value left its lane's range" of checked renormalisations, is recorded in CTC_F6_D9 diagnostic builds
     // only: benign utterances flush irrelevant values all the time -- the thin front ahead of the bulk, the tail behind it -- so it
     // flags 60 % of the N(0,1) utterances at T = 1000 and still missed one harmful case in 30 000; tests/tools/flag_stats.py)
-    const int fl = (lds.flag & (want_grad ? (3 | D8_SYNC) : (31 | 128 | D8_SYNC))) | (okP ? 0 : 1);
+    // r04: ... in the FIRST HALF OF A FORWARD / BACKWARD PAIR (ctc_amd_loss_forward: the resume call will check every utterance's
+    // posterior mass and redo what fails) only for BINDING alignments -- fewer than BIND_SLACK frames more than the labels (and,
+    // classic, their repeats) need.  The signs D3 / D4 / D7 are heuristics (no local test separates a harmful flush from the thin fronts and tails every
+    // utterance sheds all the time -- see D9), and unrestricted they sent EVERY utterance with logits as sharp as a trained model's
+    // to the log domain: the public forward + backward path ran at half speed there.  What the sound detector, the mass check D6
+    // of a call with a gradient, says about where the sweeps lose anything (tests/tools/flag_stats.py, 256 utterances per cell,
+    // U = 128, V = 3 .. 256): N(0, 3^2) logits -- 68-100 % of the utterances at slack 0 .. 2, 3-20 % at 8, 0-0.4 % at 16, NONE at
+    // 32, 64, 128, 512; N(0, 5^2): 46-73 % at 16, 2-9 % at 32, none at 64.  Non-binding utterances keep D1 / D2 only.
+    const int slack = len - ll - (KIND == 0 ? S.repeats(ll, lane) : 0);
+    const int soft = (p.resume != 2 || slack < BIND_SLACK) ? (28 | 128) : 0;  // (a stand-alone loss-only call: always)
+    const int fl = (lds.flag & (want_grad ? (3 | D8_SYNC) : (3 | soft | D8_SYNC))) | (okP ? 0 : 1);
     if (lane == 0) {
       const double dlogp = (double)flog2(s) + (double)EX - sl2;
       logp_ws[b] = okP ? dlogp : -INFINITY;
@@ -1467,7 +1485,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
   const int *ck_k = kexp_ws + ((long)b * 2 + RDIR) * nslot * 64;
   float *dump = lds.dump[2 + SIDE];
 
-  if (!p.resume) {  // phase 1: nothing to recompute yet -- this wavefront works the E stage of its side
+  if (p.resume != 1) {  // phase 1: nothing to recompute yet -- this wavefront works the E stage of its side
     using SP = P1Split<BLK, NH, NL>;
     Rows<KIND, NL, VPL, XT> W;
     W.init(p, b, lane, ll, nullptr, nullptr);
@@ -1608,7 +1626,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, const Layout &L, fl
   };
 
   // ================= phase 1: E stage with statistics =================
-  if (!p.resume) {
+  if (p.resume != 1) {
     using SP = P1Split<BLK, NH, NL>;
     if constexpr (NH == 6) {
       switch (h) {
@@ -1886,7 +1904,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused6_kernel(Problem p, La
     lds.p1_cons[0] = 0; lds.p1_cons[1] = 0;
 #pragma unroll
     for (int w_ = 0; w_ < 8; ++w_) { lds.p1_prog[0][w_] = 0; lds.p1_prog[1][w_] = 0; }
-    if (p.resume) {  // the loss-only call left the outcome of the meeting point in the workspace
+    if (p.resume == 1) {  // the loss-only call left the outcome of the meeting point in the workspace
       const int f = flag_ws[b];
       const int2 m = meet_ws[b];
       lds.flag = f; lds.feasible = (f == 0); lds.lp_int = m.x; lds.cf = __int_as_float(m.y);
@@ -1927,7 +1945,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused6_kernel(Problem p, La
   }
   // sum(loss) for the training loop, without a launch of its own (ctc_amd_loss_grad_sum): the thread that wrote loss[b] --
   // lane 0 of main chain A in either domain -- adds it in fixed point; the second call of a loss / gradient pair adds nothing
-  if (p.sum_out != nullptr && !p.resume && threadIdx.x == 0 && fl != 0) {  // redone in the log domain: its loss, not the first one
+  if (p.sum_out != nullptr && p.resume != 1 && threadIdx.x == 0 && fl != 0) {  // redone in the log domain: its loss, not the first one
     if (added) add_loss_fixed(p.sum_out, lossval, -1);
     add_loss_fixed(p.sum_out, loss[b]);
   }

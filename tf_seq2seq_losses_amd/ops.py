@@ -268,7 +268,18 @@ def loss_forward(kind: int, wrt: int, p: Prepared, keep_always: bool = False) ->
     if p.B == 0 or (not keep_always and (sel != _lib.WS_LOSS_GRAD_LOGITS or pipeline_of(kind, wrt, p) != "fused6")):
         return loss_grad(kind, wrt, p, False)[0], None
     ws = torch.empty(max(_ws_bytes(sel, kind, p), 1), dtype=torch.uint8, device=p.device)
-    loss, _ = loss_grad(kind, wrt, p, False, workspace=ws)
+    if keep_always and pipeline_of(kind, wrt, p) != "fused6":
+        loss, _ = loss_grad(kind, wrt, p, False, workspace=ws)
+        return loss, ws
+    # first half of a forward / backward pair (ctc_amd_loss_forward, ABI v5): the resume call verifies every utterance's posterior
+    # mass, so the linear-domain kernel keeps its conservative loss-only signs for binding alignments only
+    lib = _lib.load()
+    loss = torch.empty(p.B, dtype=torch.float32, device=p.device)
+    with _on_device(p.device):
+        rc = lib.ctc_amd_loss_forward(kind, wrt, _ptr(p.x), _DTYPES[p.x.dtype], p.x.stride(0), p.x.stride(1), _ptr(p.labels), p.stride,
+                                      _ptr(p.label_length), _ptr(p.logit_length), p.blank, p.B, p.T, p.V, p.U,
+                                      _ptr(loss), ws.data_ptr(), ws.numel(), _stream(p.device))
+    _lib.check(rc, "ctc_amd_loss_forward")
     return loss, ws
 
 
