@@ -14,7 +14,9 @@
  *   - The caller owns every buffer, including the workspace (size from ctc_amd_workspace_bytes).
  *     Outputs are fully overwritten.  The library keeps no global state besides a thread-local
  *     error string and the test-only tier override of ctc_amd_debug_override (never set by the product path);
- *     calls are re-entrant for distinct (stream, workspace) pairs.
+ *     calls are re-entrant for distinct (stream, workspace) pairs.  The override is a plain process-wide
+ *     variable: ctc_amd_debug_override is NOT thread-safe against calls running in other threads -- set it
+ *     between calls, from the one thread that makes them (tests and benchmarks only).
  *   - Layouts are dense row-major: logits[B][T][V] float32, labels[B][label_stride] int32,
  *     label_length[B], logit_length[B] int32, loss[B], grad[B][T][V], hess[B][T][V][T][V] float32.
  *   - `U` is a static upper bound on label_length (the reference uses the dynamic max(label_length),

@@ -27,9 +27,9 @@
 //   D2  an emission needed by the lattice (label token or blank inside label_length) below 2^-120 of the row maximum: an
 //       emission that flushes is lost by BOTH chains alike, the one loss the check D6 cannot see
 //   D6  (calls with a gradient) the posterior mass of a frame, sum over all lattice states of alpha beta / P, differs from
-//       1 by more than 1e-4.  Flushing only ever removes mass, and mass that one chain loses at (t1, s1) is still carried
-//       by the other chain on the far side of t1, so sum_s alpha_t beta_t stops being the same for all t: every frame is
-//       checked against P from the meeting point.  A loss below 1e-4 of P is below the tolerance of the gradient.
+//       1 by more than MASS_TOL = 3e-5 (ctc_linear_flags.h; each helper's LAST frame of every block is sampled).  Flushing only ever removes mass, and mass that one chain loses at (t1, s1) is still carried
+//       by the other chain on the far side of t1, so sum_s alpha_t beta_t stops being the same for all t: the sampled frames are
+//       checked against P from the meeting point.  A loss below 3e-5 of P is below the tolerance of the gradient.
 //   D5  a lane's alpha and beta exponents exceed log2 P by more than 90 in the posterior: mantissa products that underflow
 //       would no longer be negligible (see KK_MAX)
 //   D3, D4 (calls WITHOUT a gradient have no phase 2 to check the mass in; they fall back on conservative local signs)
@@ -41,6 +41,7 @@
 // 420-468, tools.py:27-40.
 #include "ctc_fused_common.h"
 #include "ctc_swap_reduce.h"
+#include "ctc_linear_flags.h"
 #include "ctc_fused5_roles.h"  // the log-domain roles: run inside this kernel for the utterances it flags
 
 #ifndef CTC_FUSED_KIND
@@ -53,8 +54,8 @@ namespace fused6 {
 
 using namespace ctc::fused;
 
-constexpr int DEAD = -(1 << 24);  // exponent of a lane whose mantissas are all zero
-constexpr int GAP = 16;           // a dead lane adopts its upstream neighbour's exponent minus GAP (per adoption level)
+using linear::DEAD; using linear::GAP; using linear::GAP_WIDE; using linear::DOWN_MAX; using linear::DECAY_MAX; using linear::KK_MAX;
+using linear::KK_MAX2; using linear::EMIS_MIN; using linear::MASS_TOL;  // (ctc_linear_flags.h: shared with ctc_hvp_fused.hip)
 #ifndef CTC_F6_GAP_LIVE
 #define CTC_F6_GAP_LIVE 16
 #endif
@@ -64,16 +65,16 @@ constexpr int GAP = 16;           // a dead lane adopts its upstream neighbour's
 // overflow, and between the frames D6 samples that went unnoticed: a gradient 3.0 off, unflagged (tests/tools/flag_stats.py, cell
 // sigma 5, V = 3, U = 32, slack 2).  With 16 per level and LV levels a mantissa stays below 2^55 and a product below 2^110.
 constexpr int GAP_LIVE = CTC_F6_GAP_LIVE;
-constexpr int GAP_WIDE = 64;      // ... when ONE level suffices (a lane of 4 or 8 label positions is never crossed within a period):
+// GAP_WIDE (ctc_linear_flags.h):      // ... when ONE level suffices (a lane of 4 or 8 label positions is never crossed within a period):
                                   // neighbouring lanes then differ by 2^100 and more on benign inputs, and lifting a lane to
                                   // 2^-16 of its neighbour pushed its own values towards the float32 underflow (D4)
 // D3 / D4: a lane's own values pushed 2^-96 below its exponent (by a larger inflow scale / by decay).  A float32 mantissa
 // holds them down to 2^-126, so nothing is lost yet; the margin is for what happens before the next renormalisation.  (64
 // was too tight once a lane spans eight label positions: neighbouring lanes then differ by more than 2^64 on benign inputs
 // and every loss-only call at U > 256 went to the log domain.)
-constexpr int DOWN_MAX = 96;      // D3
-constexpr int DECAY_MAX = 96;     // D4
-constexpr int KK_MAX = 90;        // Posterior scale 2^KK_MAX at most in ONE factor.  The posterior of a state is (alpha mantissa)(beta
+// DOWN_MAX (ctc_linear_flags.h):      // D3
+// DECAY_MAX (ctc_linear_flags.h):     // D4
+// KK_MAX (ctc_linear_flags.h):        // Posterior scale 2^KK_MAX at most in ONE factor.  The posterior of a state is (alpha mantissa)(beta
                                   // mantissa) 2^(kA + kB - log2 P); the mantissa PRODUCT underflows below 2^-126, which is harmless
                                   // while the scale stays below 2^90 (the lost term is < 2^-5 units of 2^-30) and fatal beyond --
                                   // sharp logits on a nearly forced alignment get there in the frames just before a renormalisation,
@@ -82,8 +83,8 @@ constexpr int KK_MAX = 90;        // Posterior scale 2^KK_MAX at most in ONE fac
                                   // Beyond KK_MAX the scale is applied in TWO factors: the excess 2^(k - KK_MAX) goes onto the chain's
                                   // own operand BEFORE the product (then nothing that matters underflows), the rest after it as before;
                                   // a wave-uniform branch per frame, taken only while some lane of the wavefront needs it.
-constexpr int KK_MAX2 = 200;      // D5: beyond this even the pre-scaled operand would leave float32
-constexpr float EMIS_MIN = 7.52316384526264e-37f;  // 2^-120 (D2)
+// KK_MAX2 (ctc_linear_flags.h):      // D5: beyond this even the pre-scaled operand would leave float32
+// EMIS_MIN (ctc_linear_flags.h):  // 2^-120 (D2)
 constexpr int BIND_SLACK = 64;    // loss-only calls honour the soft signs D3 / D4 / D7 below this many spare frames (see the meeting point)
 // D7 (loss-only calls): a needed emission below 2^-16 of its row maximum -- "sharp" logits.  The r03 soak runs found utterances with
 // logits N(0, 3^2) on nearly forced alignments (2..15 frames more than labels) whose linear-domain sweeps lose mass that matters later
@@ -93,11 +94,11 @@ constexpr int BIND_SLACK = 64;    // loss-only calls honour the soft signs D3 / 
 #ifdef CTC_F6_NO_D7  // (diagnostic builds: what do loss-only calls lose without the guard?)
 constexpr float EMIS_SOFT = 0.f;
 #else
-constexpr float EMIS_SOFT = 1.52587890625e-05f;    // 2^-16 (D7)
+using linear::EMIS_SOFT;                           // 2^-16 (D7)
 #endif
 // D6: tolerated deviation of a frame's posterior mass from 1.  The gradient of an unflagged utterance is off by about as much, and the
 // bar is 1e-4: with a tolerance of 1e-4 the soak runs measured up to 9.0e-5 on unflagged utterances -- no margin (r03).
-constexpr float MASS_TOL = 3e-5f;
+// MASS_TOL (ctc_linear_flags.h):
 
 #ifdef CTC_F6_STAMPS
 // diagnostic build: cycles of work / of waiting at the block barriers, per wavefront and phase (thread-private registers)
@@ -1185,7 +1186,10 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
     // U = 128, V = 3 .. 256): N(0, 3^2) logits -- 68-100 % of the utterances at slack 0 .. 2, 3-20 % at 8, 0-0.4 % at 16, NONE at
     // 32, 64, 128, 512; N(0, 5^2): 46-73 % at 16, 2-9 % at 32, none at 64.  Non-binding utterances keep D1 / D2 only.
     const int slack = len - ll - (KIND == 0 ? S.repeats(ll, lane) : 0);
-    const int soft = (p.resume != 2 || slack < BIND_SLACK) ? (28 | 128) : 0;  // (a stand-alone loss-only call: always)
+    // (a stand-alone loss-only call: always.  And always with four or eight label positions per lane: one exponent for that many
+    // states holds far less -- r04 soak, seed 101: 7 labels in 158 frames under a label bound of 300, N(0, 3^2), forward loss 1.5e-3
+    // off, caught by the resume call's D6 only -- and the table behind BIND_SLACK was measured for one and two positions per lane)
+    const int soft = (p.resume != 2 || slack < BIND_SLACK || NL > 2) ? (28 | 128) : 0;
     const int fl = (lds.flag & (want_grad ? (3 | D8_SYNC) : (3 | soft | D8_SYNC))) | (okP ? 0 : 1);
     if (lane == 0) {
       const double dlogp = (double)flog2(s) + (double)EX - sl2;

@@ -28,6 +28,7 @@
 #include "ctc_fused_common.h"
 #include "ctc_swap_reduce.h"
 #include "ctc_hvp_fused.h"
+#include "ctc_linear_flags.h"
 #include "ctc_v1_device.h"   // emit_row, scan_body: the log-domain building blocks, run in this launch for flagged utterances
 #include "ctc_hvp_device.h"  // temit_row, tscan_body, hvp_out_row
 
@@ -42,10 +43,19 @@ using namespace ctc::fused;
 
 constexpr int BLK = HVPF_BLK, NH = 3, RN = 3, NG = BLK / RN, NW = 4 + 2 * NH;  // 10 wavefronts: 4 chains + 3 helpers a side
 constexpr int V = 256;
-constexpr int DEAD = -(1 << 24);
-constexpr int GAP = 16, GAP_WIDE = 64;
-constexpr int DOWN_MAX = 96, DECAY_MAX = 96, KK_MAX = 90;
-constexpr float EMIS_MIN = 7.52316384526264e-37f;  // 2^-120 (D2)
+using linear::DEAD; using linear::GAP; using linear::GAP_WIDE; using linear::DOWN_MAX; using linear::DECAY_MAX; using linear::KK_MAX;
+using linear::EMIS_MIN; using linear::MASS_TOL;  // (ctc_linear_flags.h: one copy for this kernel and ctc_fused6.hip)
+
+// packed float32 pairs and the one-instruction inflow for the classic two-positions-per-lane chains (as ctc_fused6.hip, r04)
+typedef float f2v __attribute__((ext_vector_type(2)));
+#ifndef CTC_HVPF_PACKED
+#define CTC_HVPF_PACKED 1
+#endif
+template <int DIR>
+__device__ __forceinline__ void fmac_from_upstream(float &acc, float x, float sc) {
+  if constexpr (DIR == 0) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(sc));
+  else asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(sc));
+}
 
 __device__ __forceinline__ void block_barrier_raw() {
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed; vmcnt untouched
@@ -161,6 +171,16 @@ struct Chain {
   int k, kx, dk;
   bool norep[NL], norep_next[NL];
   int flag;
+  static constexpr bool PACKED = (CTC_HVPF_PACKED != 0) && KIND == 0 && NL == 2;
+  float nrf[NL];  // PACKED: 1.0 where the repeat rule lets the diagonal pass (norep_next for A, norep for B)
+  float sc = 1.f, scb = 0.f;  // PACKED: 2^dk as a float (0 below 2^-126), and the same on the boundary lane only
+  bool boundary = false;
+  __device__ __forceinline__ void set_scale() {
+    if constexpr (PACKED) {
+      sc = (dk < -126) ? 0.f : ldexp_f(1.f, dk < 127 ? dk : 127);
+      scb = boundary ? sc : 0.f;
+    }
+  }
   bool alive = false;
   int age = 0;
   bool relevant = true;
@@ -174,9 +194,12 @@ struct Chain {
       const int tk = tok(i);
       norep[j] = (i == 0) || tk != tok(i - 1);
       norep_next[j] = tok(i + 1) != tk;
+      nrf[j] = ((DIR == 0) ? norep_next[j] : norep[j]) ? 1.f : 0.f;
       c[j] = 0.f; o[j] = 0.f; dc[j] = 0.f; dob[j] = 0.f;
     }
     cx = 0.f; dcx = 0.f; k = DEAD; kx = DEAD; dk = 0; flag = 0;
+    boundary = lane == (DIR == 0 ? 0 : 63);
+    set_scale();
     relevant = lane * NL <= ll;
   }
 
@@ -200,7 +223,37 @@ struct Chain {
   // one lattice step, values and tangents (blank gauge: d bl = 0, d y = y w)
   __device__ __forceinline__ void step(const Emis<NL> &e) {
     const float bl = e.bl;
-    if constexpr (KIND == 0 && DIR == 0) {
+    if constexpr (PACKED && DIR == 0) {
+      // the generic recursion below, two label positions (and value + tangent side by side) per instruction
+      const f2v C = {c[0], c[1]}, O = {o[0], o[1]}, DC = {dc[0], dc[1]}, DO = {dob[0], dob[1]};
+      const f2v Y = {e.y[0], e.y[1]}, W = {e.w[0], e.w[1]}, NR = {nrf[0], nrf[1]};
+      const f2v X = __builtin_elementwise_fma(O, NR, C), DX = __builtin_elementwise_fma(DO, NR, DC);
+      const f2v M = C + O, DM = DC + DO;
+      float olo = __builtin_fmaf(cx, scb, O.x), dlo = __builtin_fmaf(dcx, scb, DO.x);
+      fmac_from_upstream<0>(olo, X.y, sc);
+      fmac_from_upstream<0>(dlo, DX.y, sc);
+      const f2v OS = {olo, O.y + X.x}, DS = {dlo, DO.y + DX.x};
+      const f2v ON = Y * OS;
+      const f2v DN = __builtin_elementwise_fma(W, ON, Y * DS);
+      const f2v CN = M * bl, DCN = DM * bl;
+      o[0] = ON.x; o[1] = ON.y; dob[0] = DN.x; dob[1] = DN.y;
+      c[0] = CN.x; c[1] = CN.y; dc[0] = DCN.x; dc[1] = DCN.y;
+      cx *= bl; dcx *= bl;
+    } else if constexpr (PACKED && DIR == 1) {
+      const f2v C = {c[0], c[1]}, O = {o[0], o[1]}, DC = {dc[0], dc[1]}, DO = {dob[0], dob[1]};
+      const f2v Y = {e.y[0], e.y[1]}, W = {e.w[0], e.w[1]}, NR = {nrf[0], nrf[1]};
+      const f2v H = C * bl, DH = DC * bl;
+      const f2v EE = Y * O;
+      const f2v DEE = __builtin_elementwise_fma(W, EE, Y * DO);
+      const f2v PN = H + EE, DPN = DH + DEE;
+      const f2v X = __builtin_elementwise_fma(EE, NR, H), DX = __builtin_elementwise_fma(DEE, NR, DH);
+      cx *= bl; dcx *= bl;
+      float ohi = __builtin_fmaf(cx, scb, EE.y), dhi = __builtin_fmaf(dcx, scb, DEE.y);
+      fmac_from_upstream<1>(ohi, X.x, sc);
+      fmac_from_upstream<1>(dhi, DX.x, sc);
+      o[0] = EE.x + X.y; o[1] = ohi; dob[0] = DEE.x + DX.y; dob[1] = dhi;
+      c[0] = PN.x; c[1] = PN.y; dc[0] = DPN.x; dc[1] = DPN.y;
+    } else if constexpr (KIND == 0 && DIR == 0) {
       float m[NL], x[NL], dm[NL], dx[NL];
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
@@ -289,7 +342,8 @@ struct Chain {
       const int nb = (DIR == 0) ? from_prev_lane_i(kn, ex) : from_next_lane_i(kn, ex);
       kn = imax(kn, nb - (LV == 1 ? GAP_WIDE : GAP));
     }
-    if (__builtin_amdgcn_ballot_w64(!live && relevant) != 0) {
+    {  // every level for every lane, with or without mass (r04, as ctc_fused6.hip: a steep profile of live lanes kept exponents 2^100
+       // apart two lanes down after the one level, and the inflow overflowed when the bulk crossed two lanes within a period)
 #pragma unroll
       for (int lv = 1; lv < LV; ++lv) {
         const int nb = (DIR == 0) ? from_prev_lane_i(kn, ex) : from_next_lane_i(kn, ex);
@@ -309,6 +363,7 @@ struct Chain {
     cx = ldexp_f(cx, kx - ex); dcx = ldexp_f(dcx, kx - ex);
     kx = ex;
     dk = ((DIR == 0) ? from_prev_lane_i(k, kx) : from_next_lane_i(k, kx)) - k;
+    set_scale();
     alive = live;
   }
   __device__ __forceinline__ int flag_or() const {
@@ -354,6 +409,7 @@ __device__ __forceinline__ void restore(Chain<KIND, NL, DIR> &S, const CkRow<NL>
   }
   S.cx = ck.r.cx; S.dcx = ck.r.dcx; S.k = ck.k; S.kx = ck.r.kx;
   S.dk = ((DIR == 0) ? from_prev_lane_i(S.k, S.kx) : from_next_lane_i(S.k, S.kx)) - S.k;
+  S.set_scale();
   S.alive = m > 0.f;
 }
 
@@ -1020,7 +1076,7 @@ __device__ __forceinline__ void run_helper(const Problem &p, float4 *__restrict_
       for (int q = 0; q < N2; ++q) {
         const int d = P2 + q;
         if (d < nv) {
-          massbad |= !(fabsf(readlane_f(qall, SwapLanes<4>::lane(q)) - 1073741824.0f) < 1073741824.0f * 1e-4f);  // D6
+          massbad |= !(fabsf(readlane_f(qall, SwapLanes<4>::lane(q)) - 1073741824.0f) < 1073741824.0f * MASS_TOL);  // D6
           const float4 ev = S.expo(XG[r][q], SG[r][q].x);
           S.out_row(geo.frame(DIR, g, d), readlane_f(dball, SwapLanes<4>::lane(q)), dqt[q], readlane_f(aall, SwapLanes<4>::lane(q)), ev, VG[r][q],
                     SG[r][q].y, SG[r][q].z);

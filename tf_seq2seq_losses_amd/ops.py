@@ -63,6 +63,7 @@ class Prepared:
             if t.dtype == torch.int32 and t.device == dev and t.is_contiguous():
                 return t
             return t.to(device=dev, dtype=torch.int32).contiguous()
+        src_label_length = label_length  # (the caller's own tensor: what the cache of its maximum is keyed on)
         self.labels, self.label_length, self.logit_length = i32(labels), i32(label_length), i32(logit_length)
         self.blank = int(blank_index)
         self.B, self.T, self.V = (int(s) for s in x.shape)
@@ -76,14 +77,27 @@ class Prepared:
             U = self.stride
             if host_max_label_length is not None:
                 U = max(0, min(U, int(host_max_label_length)))
-            elif U > WIDTH_WORTH_A_LOOK and self.label_length.numel() > 0 and not torch.cuda.is_current_stream_capturing():
-                U = max(0, min(U, _device_max_label_length(self.label_length)))
+            elif U > WIDTH_WORTH_A_LOOK and self.label_length.numel() > 0:
+                # the maximum of the CALLER's tensor: a host tensor costs nothing; a device tensor one sync per tensor object and
+                # version (keyed on the caller's object -- the converted copy made above is a new object every call and never hit
+                # the cache); under stream capture no sync is possible and the width stands
+                if not src_label_length.is_cuda:
+                    U = max(0, min(U, int(src_label_length.max())))
+                elif not torch.cuda.is_current_stream_capturing():
+                    U = max(0, min(U, _device_max_label_length(src_label_length)))
         self.U = int(U)
         self.device = dev
 
     def plain(self) -> "Prepared":
-        """The same inputs with contiguous float32 logits (Hessian, HVP and alpha/beta read that format only)."""
+        """The same inputs with contiguous float32 logits (Hessian, HVP and alpha/beta read that format only), 16-byte aligned
+        (ctc_amd_hvp / ctc_amd_hessian refuse other base pointers: a batch-sliced view whose offset is not a multiple of 16 bytes is
+        copied once here)."""
         if not self.native:
+            if self.x.numel() > 0 and (self.x.data_ptr() & 15) != 0:
+                q = Prepared.__new__(Prepared)
+                q.__dict__.update(self.__dict__)
+                q.x = self.x.clone()
+                return q
             return self
         q = Prepared.__new__(Prepared)
         q.__dict__.update(self.__dict__)
@@ -374,6 +388,8 @@ def hvp(kind: int, wrt: int, p: Prepared, vec: torch.Tensor, want_grad: bool = F
     p = p.plain()
     assert tuple(vec.shape) == (p.B, p.T, p.V), f"vec must be [B,T,V] = {(p.B, p.T, p.V)}, got {tuple(vec.shape)}"
     vec = vec.to(device=p.device, dtype=torch.float32).contiguous()
+    if vec.numel() > 0 and (vec.data_ptr() & 15) != 0:  # (an offset view: ctc_amd_hvp wants 16-byte aligned rows)
+        vec = vec.clone()
     loss = torch.empty(p.B, dtype=torch.float32, device=p.device)
     grad = torch.empty((p.B, p.T, p.V), dtype=torch.float32, device=p.device) if want_grad else None
     out = torch.empty((p.B, p.T, p.V), dtype=torch.float32, device=p.device)
