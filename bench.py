@@ -683,7 +683,7 @@ def main():
             # HBM bytes per launch from committed rocprofv3 PMC passes of this configuration (FETCH_SIZE x2 + WRITE_SIZE, see the
             # file's note).  Only quoted when the profiled kernel is the one this run launches (name with template arguments).
             traffic, traffic_src = None, None
-            tfile = os.path.join(ROOT, "profiles", "r03_fused6_pmc_traffic.json")
+            tfile = os.path.join(ROOT, "profiles", "r04_fused6_pmc_traffic.json")
             north_star = args.kind == "classic" and (B, T, U, V) == (256, 1000, 128, 256) and not args.ragged and args.dtype == "f32" and not args.time_major
             if north_star and os.path.exists(tfile):
                 prof = json.load(open(tfile))
