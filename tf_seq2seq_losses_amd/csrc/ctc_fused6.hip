@@ -1928,11 +1928,28 @@ __global__ __launch_bounds__(64 * (4 + 2 * NH)) void fused6_kernel(Problem p, La
   } else if (w == 3) {
     __builtin_amdgcn_s_setprio(2);
     run_recompute<KIND, NL, NH, BLK, VPL, 1, XT>(p, L, alpha_ws, beta_ws, kexp_ws, stats_ws, sink_ws, lds, geo, grad != nullptr, b, flag_ws);
-  } else if (w < 4 + NH) {
-    run_helper<KIND, NL, NH, BLK, VPL, 0, XT>(p, L, stats_ws, sink_ws, d_loss, grad, lds, geo, w - 4, b, flag_ws);
   } else {
-    if (CTC_F6_HPRIO_B != 0) __builtin_amdgcn_s_setprio(CTC_F6_HPRIO_B);
-    run_helper<KIND, NL, NH, BLK, VPL, 1, XT>(p, L, stats_ws, sink_ws, d_loss, grad, lds, geo, w - 4 - NH, b, flag_ws);
+    // which helper a wavefront is.  Wavefronts go to the SIMDs in the order 0, 2, 1, 3, 0, ... and a SIMD prefers its OLDER wavefronts:
+    // with the plain order (side A = wavefronts 4 .. 3+NH, side B after them) the side-B helpers are the youngest wavefront of every
+    // SIMD (r04 stamps: 82-85 us of work in phase 2 against 66-70 for side A).  CTC_F6_ROLEMAP (experiment builds): other orders.
+#ifndef CTC_F6_ROLEMAP
+#define CTC_F6_ROLEMAP 0
+#endif
+    int hs = (w - 4) / NH, hh = (w - 4) % NH;  // (side, index): the plain order
+    if constexpr (CTC_F6_ROLEMAP == 1 && NH == 4) {        // A0 A1 B0 B1 A2 A3 B2 B3: side A beside the main chains, side B beside the recompute chains
+      const int q = w - 4; hs = (q >> 1) & 1; hh = (q & 1) + 2 * (q >> 2);
+    } else if constexpr (CTC_F6_ROLEMAP == 2) {             // side B first (older)
+      hs = 1 - hs;
+    } else if constexpr (CTC_F6_ROLEMAP == 3 && NH == 4) {  // A0 B0 A1 B1 A2 B2 A3 B3
+      const int q = w - 4; hs = q & 1; hh = q >> 1;
+    }
+    hs = __builtin_amdgcn_readfirstlane(hs); hh = __builtin_amdgcn_readfirstlane(hh);
+    if (hs == 0) {
+      run_helper<KIND, NL, NH, BLK, VPL, 0, XT>(p, L, stats_ws, sink_ws, d_loss, grad, lds, geo, hh, b, flag_ws);
+    } else {
+      if (CTC_F6_HPRIO_B != 0) __builtin_amdgcn_s_setprio(CTC_F6_HPRIO_B);
+      run_helper<KIND, NL, NH, BLK, VPL, 1, XT>(p, L, stats_ws, sink_ws, d_loss, grad, lds, geo, hh, b, flag_ws);
+    }
   }
   // Utterances the linear domain cannot hold (flags D1..D6, normally none): the same wavefronts redo them in the log
   // domain right here -- same roles, the LDS reused, every output row rewritten -- instead of a second launch that
