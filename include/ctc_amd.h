@@ -269,7 +269,12 @@ int ctc_amd_loss_grad_sum(int kind, int wrt,
  * linear-domain kernel hands to its log-domain roles.  A loss-only call has no posterior mass to check its sweeps against; a
  * stand-alone one (ctc_amd_loss_grad* with grad == NULL: inference, scoring) therefore sends every utterance that shows one of
  * the kernel's conservative signs there -- which includes every utterance with logits as sharp as a trained model's (D7).  This
- * call honours those signs only for BINDING alignments (fewer than 64 frames to spare over what the labels need): the resume
+ * call trusts the linear sweeps' loss only where the sound detector (the posterior mass check of calls with a gradient) finds
+ * nothing to redo -- at least 64 frames to spare over what the labels need, at most 12 frames per label position, P decaying by at
+ * most 10 bits per frame (11.75 on the simplified lattice: logits up to about N(0, 3.25^2) over 256 tokens), one or two label
+ * positions per lane (U <= 128) -- and keeps every sign outside those bounds.  Every loss-only call, stand-alone or first half, also
+ * takes the log-domain roles for an utterance with more than 40 frames per label position when lanes hold two or more label
+ * positions (U > 64; flag 2048).  The resume
  * call checks every utterance's posterior mass and redoes what fails, so the gradient is always verified; the loss of a
  * non-binding utterance is taken from the linear sweeps as it stands (measured: tests/tools/flag_stats.py).
  * Shapes that do not run the linear-domain fused kernel behave exactly like ctc_amd_loss_grad_ex with grad == NULL.

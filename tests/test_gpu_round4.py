@@ -59,7 +59,7 @@ def test_sharp_logits_at_the_north_star_shape_stay_in_the_linear_domain(kind):
 
 def test_loss_only_calls_send_binding_sharp_alignments_to_the_log_domain_and_no_others():
     """The first half of a forward / backward pair (ctc_amd_loss_forward) honours the soft signs D3 / D4 / D7 for binding alignments
-    only (fewer than 64 spare frames); a stand-alone loss-only call honours them always."""
+    (fewer than 64 spare frames) and not inside its three bounds; a stand-alone loss-only call honours them always."""
     from tf_seq2seq_losses_amd import ops, _lib
     rng = np.random.default_rng(3)
     B, U, V = 64, 100, 64
@@ -190,3 +190,68 @@ def test_forward_half_keeps_every_sign_with_many_label_positions_per_lane():
     grad = ops.grad_resume(0, _lib.WRT_LOGITS, p, ws)
     assert abs(float(loss[0]) - rl[0]) < 1e-4 * max(1.0, abs(rl[0]))
     assert np.abs(grad.cpu().numpy() - rg).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_loss_only_calls_with_long_dwell_on_mild_logits_take_the_log_domain():
+    """2-3 labels in 512 frames under a label bound of 128 (two label positions per lane), N(0, 2^2) logits over 29 tokens: the
+    soft signs D3/D4/D5/D7 miss 22 % of these utterances, and r03 / early r04 builds returned 2 of 256 losses more than 1e-4 off
+    (tests/tools/flag_stats_short_labels.py).  D10 (> 40 frames per label position, loss-only calls) sends all of them to the
+    log-domain roles."""
+    from tf_seq2seq_losses_amd import ops, _lib
+    rng = np.random.default_rng(5)
+    B, T, U, V = 256, 512, 128, 29
+    labels = rng.integers(1, V, (B, U), dtype=np.int32)
+    ll = rng.integers(2, 4, B).astype(np.int32)
+    tl = np.full(B, T, np.int32)
+    logits = (rng.standard_normal((B, T, V)) * 2.0).astype(np.float32)
+    rl, _ = C.loss_grad("classic", labels, logits, ll, tl, 0)
+    p = ops.Prepared(_t(labels), _t(logits), _t(ll), _t(tl), 0, U=U)
+    ws = ops._workspace(_lib.WS_LOSS_GRAD_LOGITS, 0, p)
+    loss, _ = ops.loss_grad(0, _lib.WRT_LOGITS, p, False, workspace=ws)
+    fl = ops.fused_flags(ws, 0, p).cpu().numpy()
+    assert (fl & 2048).all(), np.unique(fl)
+    assert (np.abs(loss.cpu().numpy() - rl) / np.maximum(1, np.abs(rl))).max() < 1e-4
+    # the forward half of a pair: same rule (dwell > 12), same accuracy
+    loss2, ws2 = ops.loss_forward(0, _lib.WRT_LOGITS, p)
+    assert (np.abs(loss2.cpu().numpy() - rl) / np.maximum(1, np.abs(rl))).max() < 1e-4
+
+
+def test_forward_half_trusts_the_linear_sweeps_only_inside_its_three_bounds():
+    """ctc_amd_loss_forward lets the linear sweeps' loss stand only where the mass check of calls with a gradient finds nothing to
+    redo: >= 64 spare frames, <= 12 frames per label position, P decaying by <= 10 bits per frame (11.75 on the simplified lattice)
+    (and <= 2 label positions per lane).  Outside any of the three it keeps every soft sign, like a stand-alone call.  Cases:
+    N(0, 5^2) logits over 256 tokens (decay 15 bits per frame), 2 labels in 199 frames (dwell 66: tests/golden/r04_case_forward_loss_dwell.npz, r04 soak seed 106 -- the state that
+    carries the posterior sits 2^-105 below a lane-mate, forward loss 1235.84 for 1234.70), and N(0, 3^2) inside the bounds."""
+    import os
+    from tf_seq2seq_losses_amd import ops, _lib
+    rng = np.random.default_rng(21)
+    B, T, U, V = 48, 400, 100, 256
+    labels = rng.integers(1, V, (B, U), dtype=np.int32)
+    ll, tl = np.full(B, U, np.int32), np.full(B, T, np.int32)
+    for sigma, trusted in ((5.0, False), (3.0, True)):
+        logits = (rng.standard_normal((B, T, V)) * sigma).astype(np.float32)
+        p = ops.Prepared(_t(labels), _t(logits), _t(ll), _t(tl), 0, U=U)
+        loss, ws = ops.loss_forward(0, _lib.WRT_LOGITS, p)
+        fl = ops.fused_flags(ws, 0, p).cpu().numpy()
+        grad = ops.grad_resume(0, _lib.WRT_LOGITS, p, ws)
+        rl, rg = C.loss_grad("classic", labels, logits, ll, tl, 0)
+        assert (np.abs(loss.cpu().numpy() - rl) / np.maximum(1, np.abs(rl))).max() < 1e-4
+        assert np.abs(grad.cpu().numpy() - rg).max() < 2e-4  # (the log-domain roles' own accuracy on N(0, 5^2) logits: DESIGN.md section 2)
+        if trusted:
+            assert not fl.any(), np.unique(fl)
+        else:
+            assert (fl & 128).all(), np.unique(fl)
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "r04_case_forward_loss_dwell.npz"), allow_pickle=True)
+    x, lab, ll1, tl1, U1 = d["x"], d["labels"], d["ll"], d["tl"], int(d["U"])
+    rl, rg = C.loss_grad("classic", lab, x, ll1, tl1, 0)
+    p = ops.Prepared(_t(lab), _t(x), _t(ll1), _t(tl1), 0, U=U1)
+    loss, ws = ops.loss_forward(0, _lib.WRT_LOGITS, p)
+    grad = ops.grad_resume(0, _lib.WRT_LOGITS, p, ws)
+    assert abs(float(loss[0]) - rl[0]) < 1e-4 * max(1.0, abs(rl[0]))
+    assert np.abs(grad.cpu().numpy() - rg).max() < 1e-4
+    # a stand-alone loss-only call on the same utterance: more than 40 frames per label position is a sign of its own (D10 = 2048)
+    ws = ops._workspace(_lib.WS_LOSS_GRAD_LOGITS, 0, p)
+    loss1, _ = ops.loss_grad(0, _lib.WRT_LOGITS, p, False, workspace=ws)
+    assert int(ops.fused_flags(ws, 0, p)[0]) & 2048
+    assert abs(float(loss1[0]) - rl[0]) < 1e-4 * max(1.0, abs(rl[0]))

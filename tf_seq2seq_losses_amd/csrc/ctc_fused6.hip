@@ -85,7 +85,13 @@ constexpr int GAP_LIVE = CTC_F6_GAP_LIVE;
                                   // a wave-uniform branch per frame, taken only while some lane of the wavefront needs it.
 // KK_MAX2 (ctc_linear_flags.h):      // D5: beyond this even the pre-scaled operand would leave float32
 // EMIS_MIN (ctc_linear_flags.h):  // 2^-120 (D2)
-constexpr int BIND_SLACK = 64;    // loss-only calls honour the soft signs D3 / D4 / D7 below this many spare frames (see the meeting point)
+// where the forward half of a pair trusts the linear sweeps (see the meeting point): at least BIND_SLACK spare frames, at most
+// DWELL_MAX frames per label position, P decaying by at most RATE_MAX_X4 / 4 bits per frame (per lattice kind)
+// (decay rate, north-star shape: classic 9.0 bits per frame at N(0, 3^2) -- nothing redone; 9.8 at 3.25^2 -- nothing; 10.5 at 3.5^2 --
+// 5 %; 12.1 at 4^2 -- 51 %.  Simplified: 10.7 / 11.6 -- nothing; 12.4 -- 6 %; 13.3 -- 50 %.)
+constexpr int BIND_SLACK = 64, DWELL_MAX = 12, RATE_MAX_X4_CLASSIC = 40, RATE_MAX_X4_SIMPLIFIED = 47;
+constexpr int DWELL_HARD = 40;      // D10: loss-only calls with more frames per label position than this take the log-domain roles
+constexpr int D10_DWELL = 2048;
 // D7 (loss-only calls): a needed emission below 2^-16 of its row maximum -- "sharp" logits.  The r03 soak runs found utterances with
 // logits N(0, 3^2) on nearly forced alignments (2..15 frames more than labels) whose linear-domain sweeps lose mass that matters later
 // WITHOUT tripping D1..D5 (loss off by 1e-4 .. 3e-2 relative): a call with a gradient sees it in the posterior mass (D6) and redoes the
@@ -1178,19 +1184,30 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
     // only: benign utterances flush irrelevant values all the time -- the thin front ahead of the bulk, the tail behind it -- so it
     // flags 60 % of the N(0,1) utterances at T = 1000 and still missed one harmful case in 30 000; tests/tools/flag_stats.py)
     // r04: ... in the FIRST HALF OF A FORWARD / BACKWARD PAIR (ctc_amd_loss_forward: the resume call will check every utterance's
-    // posterior mass and redo what fails) only for BINDING alignments -- fewer than BIND_SLACK frames more than the labels (and,
-    // classic, their repeats) need.  The signs D3 / D4 / D7 are heuristics (no local test separates a harmful flush from the thin fronts and tails every
-    // utterance sheds all the time -- see D9), and unrestricted they sent EVERY utterance with logits as sharp as a trained model's
-    // to the log domain: the public forward + backward path ran at half speed there.  What the sound detector, the mass check D6
-    // of a call with a gradient, says about where the sweeps lose anything (tests/tools/flag_stats.py, 256 utterances per cell,
-    // U = 128, V = 3 .. 256): N(0, 3^2) logits -- 68-100 % of the utterances at slack 0 .. 2, 3-20 % at 8, 0-0.4 % at 16, NONE at
-    // 32, 64, 128, 512; N(0, 5^2): 46-73 % at 16, 2-9 % at 32, none at 64.  Non-binding utterances keep D1 / D2 only.
+    // posterior mass and redo what fails) only where the sound detector, the mass check D6 of calls with a gradient, finds
+    // something to redo -- measured over ~100 000 utterances (tests/tools/flag_stats.py, flag_stats_short_labels.py; U <= 128,
+    // V = 3 .. 256, N(0, 1 .. 5^2) logits; profiles/r04_flag_stats_*.log).  The signs D3 / D4 / D7 are heuristics (no local test
+    // separates a harmful flush from the thin fronts and tails every utterance sheds all the time -- see D9), and unrestricted they
+    // sent EVERY utterance with logits as sharp as a trained model's to the log domain: the public forward + backward path ran at
+    // half speed there.  What makes the sweeps lose mass is (a) a BINDING alignment -- N(0, 3^2): 68-100 % of the utterances redone
+    // at 0 .. 2 spare frames, 3-20 % at 8, 0-0.4 % at 16, none at 32 .. 512; (b) LONG DWELL -- few labels in many frames force long
+    // runs of blanks whatever their probability: at 16 frames per label 0.4-0.8 % redone, at 32 6-45 %, at 170 100 % (also at
+    // N(0, 2^2): 40 %); none at <= 12; (c) SHARPNESS itself -- P decaying by more than ~10 (classic) / ~12 (simplified) bits per
+    // frame (N(0, 4^2): half of the north-star utterances redone; N(0, 3^2) decays by 9.0 / 10.7, N(0, 3.5^2) by 10.5 / 12.4).  The forward half trusts the linear sweeps
+    // only inside all three bounds, with one or two label positions per lane; everything else keeps every sign, like a
+    // stand-alone loss-only call (and like r03).
     const int slack = len - ll - (KIND == 0 ? S.repeats(ll, lane) : 0);
-    // (a stand-alone loss-only call: always.  And always with four or eight label positions per lane: one exponent for that many
-    // states holds far less -- r04 soak, seed 101: 7 labels in 158 frames under a label bound of 300, N(0, 3^2), forward loss 1.5e-3
-    // off, caught by the resume call's D6 only -- and the table behind BIND_SLACK was measured for one and two positions per lane)
-    const int soft = (p.resume != 2 || slack < BIND_SLACK || NL > 2) ? (28 | 128) : 0;
-    const int fl = (lds.flag & (want_grad ? (3 | D8_SYNC) : (3 | soft | D8_SYNC))) | (okP ? 0 : 1);
+    const int decay = -(EX + frexp_e(s));                      // bits by which the unnormalised P has decayed over the utterance
+    const bool trusted = p.resume == 2 && NL <= 2 && slack >= BIND_SLACK && len <= DWELL_MAX * (ll + 1) &&
+                         4 * decay <= (KIND == 0 ? RATE_MAX_X4_CLASSIC : RATE_MAX_X4_SIMPLIFIED) * len;
+    const int soft = trusted ? 0 : (28 | 128);
+    // D10 (every loss-only call, two and more label positions per lane): more than DWELL_HARD frames per label position.  The soft
+    // signs miss what long dwell does to MILD logits -- N(0, 2^2), 2 labels in 512 frames under a label bound of 128: 17-40 % of
+    // the utterances fail the mass check of a call with a gradient, 22 % show no soft sign, and 2 of 256 stand-alone loss-only
+    // calls returned a loss more than 1e-4 off (r04, tests/tools/flag_stats_short_labels.py; r03's rules had the same hole).
+    // Nothing is redone at 30 frames per label position, 0-1.6 % at 57.
+    const int hard = (!want_grad && NL >= 2 && okP && len > DWELL_HARD * (ll + 1)) ? D10_DWELL : 0;
+    const int fl = (lds.flag & (want_grad ? (3 | D8_SYNC) : (3 | soft | D8_SYNC))) | (okP ? 0 : 1) | hard;
     if (lane == 0) {
       const double dlogp = (double)flog2(s) + (double)EX - sl2;
       logp_ws[b] = okP ? dlogp : -INFINITY;
