@@ -209,21 +209,25 @@ def emulated_collective_table(lib, step_sum_factory, device, steps=120):
     item 5): does a kernel of RCCL's footprint run beside 256 workgroups that hold 159 000 of 163 840 bytes of LDS each?"""
     from tf_seq2seq_losses_amd import dist as cdist
     out = {}
-    for name, depth, emu_kw in (("no_collective", 1, None), ("emulated_depth1", 1, {}), ("emulated_depth2", 2, {}),
-                                ("emulated_depth1_one_wave_no_lds", 1, dict(threads=64, lds=0))):
-        step = step_sum_factory(depth + 2)
+    for name, depth, emu_kw, every in (("no_collective", 1, None, 1), ("emulated_depth1", 1, {}, 1), ("emulated_depth2", 2, {}, 1),
+                                       ("emulated_depth1_one_wave_no_lds", 1, dict(threads=64, lds=0), 1),
+                                       ("emulated_depth2_every4", 2, {}, 4), ("emulated_depth2_every8", 2, {}, 8)):
+        step = step_sum_factory((depth + 2) * every)
+        kw = dict(every=every, group_view=step.view) if every > 1 else {}
         emu = EmulatedAllReduce(lib, device, **emu_kw) if emu_kw is not None else None
-        prewarm(lambda: cdist.pipelined_steps(step, 4, reduced=True, depth=depth, all_reduce=emu), 40.0)
+        prewarm(lambda: cdist.pipelined_steps(step, 4 * every, reduced=True, depth=depth, all_reduce=emu, **kw), 40.0)
+        step.reset()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        cdist.pipelined_steps(step, steps, reduced=True, depth=depth, all_reduce=emu)
+        cdist.pipelined_steps(step, steps, reduced=True, depth=depth, all_reduce=emu, **kw)
         b.record()
         torch.cuda.synchronize()
         out[name] = dict(wall_us_per_step=round((time.perf_counter() - t0) / steps * 1e6, 2), device_us_per_step=round(a.elapsed_time(b) / steps * 1e3, 2))
     out["what"] = ("loss+gradient step (ctc_amd_loss_grad_sum) in dist.pipelined_steps on one GPU; emulated = a 512-thread, 4 KB-LDS kernel polling "
-                   "for 12 us on a second stream per step, ordered like RCCL's all-reduce (tf_seq2seq_losses_amd/dist.py)")
+                   "for 12 us on a second stream per step (every4 / every8: per 4 / 8 steps, their pairs in one collective -- bench.py --reduce-every), "
+                   "ordered like RCCL's all-reduce (tf_seq2seq_losses_amd/dist.py)")
     return out
 
 
@@ -250,7 +254,7 @@ def _sum_step_factory(lib, _lib, ops, device, rank, nbuf, B=256, T=1000, U=128, 
     ws = torch.empty(_lib.workspace_bytes(_lib.WS_LOSS_GRAD_LOGITS, 0, B, T, V, U), dtype=torch.uint8, device=device)
     loss = torch.empty(B, dtype=torch.float32, device=device)
     grad = torch.empty((B, T, V), dtype=torch.float32, device=device)
-    sums = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(nbuf)]
+    sums = torch.zeros((nbuf, 2), dtype=torch.int64, device=device)
     x = dev["logits"]
     args = (0, _lib.WRT_LOGITS, x.data_ptr(), _lib.F32, x.stride(0), x.stride(1), prep.labels.data_ptr(), prep.stride,
             prep.label_length.data_ptr(), prep.logit_length.data_ptr(), 0, B, T, V, U, loss.data_ptr(), grad.data_ptr(),
@@ -264,6 +268,12 @@ def _sum_step_factory(lib, _lib, ops, device, rank, nbuf, B=256, T=1000, U=128, 
                                        torch.cuda.current_stream().cuda_stream)
         assert rc == 0
         return sums[k]
+
+    def reset():  # (a new loop starts at row 0 with every row clear)
+        state["i"] = 0
+        sums.zero_()
+    step.view = lambda first, n: sums[first % nbuf:first % nbuf + n]
+    step.reset = reset
     return step
 
 
@@ -473,6 +483,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (simplified, ragged, drop-in autograd, HVP, Hessian)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="element type of logits and gradient (producer format)")
     ap.add_argument("--time-major", action="store_true", help="logits stored [T,B,V] (producer format), passed as a strided view")
+    ap.add_argument("--reduce-every", type=int, default=8,
+                    help="the [sum(loss), count] pairs of this many consecutive steps go out in ONE all-reduce (fewer, larger collectives: "
+                         "what a collective costs the loss kernels is the event / stream-wait pair around it, secondary.emulated_collective); "
+                         "1 = one all-reduce per step")
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="steps the all-reduce of sum(loss) may lag behind the loss kernel (dist.pipelined_steps depth)")
     ap.add_argument("--emulate-collective", action="store_true",
@@ -541,8 +555,9 @@ def main():
         lib = _lib.load()
         # sum(loss) and the finite count of a step, accumulated by the loss kernel itself in fixed point: three int64[2] buffers
         # in rotation (step i fills i mod 3 and clears (i+1) mod 3; the collective of step i-1 may still be reading (i-1) mod 3)
-        NBUF = args.pipeline_depth + 2
-        sums = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(NBUF)]
+        # (--reduce-every R: the pairs of R consecutive steps go out in one all-reduce -- R rows per group, depth + 2 groups)
+        NBUF = (args.pipeline_depth + 2) * args.reduce_every
+        sums = torch.zeros((NBUF, 2), dtype=torch.int64, device=device)
         native = args.dtype != "f32" or args.time_major
         if native:  # producer formats through ctc_amd_loss_grad_ex: no conversion pass anywhere
             xf = dev["logits"].to(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
@@ -635,8 +650,10 @@ def main():
     # per step: ONE launch (loss + gradient + the [sum(loss), #finite] pair, ctc_amd_loss_grad_sum) + (N > 1) one asynchronous
     # all-reduce of the pair; the Hessian workload keeps the separate ctc_amd_reduce_loss launch
     seen = []
+    grouped = in_kernel_sum and args.reduce_every > 1
     cdist.pipelined_steps(timed_step, args.steps, reduced=in_kernel_sum, depth=args.pipeline_depth, all_reduce=emu,
-                          consume=(lambda i, pair: seen.append(pair) if i == args.steps - 1 else None) if in_kernel_sum else None)
+                          consume=(lambda i, pair: seen.append(pair.reshape(-1, 2)[-1]) if i == args.steps - 1 else None) if in_kernel_sum else None,
+                          **(dict(every=args.reduce_every, group_view=lambda first, n: sums[first % NBUF:first % NBUF + n]) if grouped else {}))
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -701,8 +718,12 @@ def main():
             "config": {"workload": f"{args.kind}_ctc_loss {'hessian' if args.hessian else 'loss+grad'} B={B} T={T} U={U} V={V} {'fp32' if args.dtype == 'f32' else 'bf16 logits/gradient, fp32 arithmetic'} per GPU"
                                    + (" ragged" if args.ragged else " full-length") + (" time-major [T,B,V]" if args.time_major else ""),
                        "global_batch": B * world,
-                       "parallelism": f"batch-sharded x{world}, all-reduce of sum(loss) {args.pipeline_depth} step(s) behind"
-                                      + (" (EMULATED on one GPU: ctc_amd_probe_spin on a second stream)" if emu is not None else "")},
+                       "parallelism": (f"batch-sharded x{world}, every step's sum(loss) pair all-reduced, {args.reduce_every} steps' pairs per collective, "
+                                       f"waited for {args.pipeline_depth} collective(s) later"
+                                       if args.reduce_every > 1 and not args.hessian else
+                                       f"batch-sharded x{world}, all-reduce of sum(loss) {args.pipeline_depth} step(s) behind")
+                                      + (" (EMULATED on one GPU: ctc_amd_probe_spin on a second stream)" if emu is not None else ""),
+                       "reduce_every": args.reduce_every},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src if not args.hessian else None,
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": alg_bytes,

@@ -99,6 +99,35 @@ def _loop_worker(rank, world, port, out):
         return bufs4[i % 4]
     assert cdist.pipelined_steps(step_reduced2, 7, reduced=True, depth=2, consume=lambda i, pair: got2.__setitem__(i, pair.tolist())) == []
     assert got2 == got
+    # fewer, larger collectives (bench.py --reduce-every 3): the pairs of three steps go out in one all-reduce; (depth + 2) * 3
+    # rows in rotation, the last group is one step short... of nothing here: 7 = 3 + 3 + 1
+    calls["n"] = 0
+    for every, depth in ((3, 1), (2, 2)):
+        calls["n"] = 0
+        nrow = (depth + 2) * every
+        rows = torch.zeros((nrow, 2), dtype=torch.int64)
+        got3, sizes = {}, []
+
+        def step_rows():
+            i = calls["n"]
+            loss = step()
+            fin = torch.isfinite(loss)
+            rows[(i + 1) % nrow].zero_()
+            rows[i % nrow] += torch.stack([torch.round(loss[fin].double() * 1048576.0).sum().long(), fin.sum()])
+            return rows[i % nrow]
+
+        def view(first, n):
+            a = first % nrow
+            assert a + n <= nrow
+            return rows[a:a + n]
+
+        def take(i, grp):
+            sizes.append(int(grp.shape[0]))
+            for j in range(grp.shape[0]):
+                got3[i - grp.shape[0] + 1 + j] = grp[j].tolist()
+        assert cdist.pipelined_steps(step_rows, 7, reduced=True, depth=depth, every=every, group_view=view, consume=take) == []
+        assert got3 == got, (every, depth)
+        assert sizes == [every] * (7 // every) + ([7 % every] if 7 % every else [])
     out[rank] = [p.tolist() for p in pairs]
     dist.destroy_process_group()
 

@@ -58,7 +58,7 @@ def all_reduce_pair(local_loss: torch.Tensor, group=None, async_op: bool = False
 
 def pipelined_steps(step: Callable[[], torch.Tensor], steps: int, group=None, reduced: bool = False,
                     consume: Callable[[int, torch.Tensor], None] = None, depth: int = 1,
-                    all_reduce: Callable = None):
+                    all_reduce: Callable = None, every: int = 1, group_view: Callable[[int, int], torch.Tensor] = None):
     """The data-parallel loop of bench.py: every step computes this rank's losses and issues the all-reduce of its
     [sum, count] pair asynchronously; the pair of step i-depth is waited for after step i has been launched, so the
     collective (two numbers, latency-bound) runs beside the next `depth` kernels.  Returns the list of reduced pairs, all
@@ -72,8 +72,16 @@ def pipelined_steps(step: Callable[[], torch.Tensor], steps: int, group=None, re
 
     all_reduce: stand-in for dist.all_reduce(buf, async_op=True) returning an object with .wait() (bench.py
     --emulate-collective measures the loop on one GPU with a kernel of RCCL's footprint); default: the real collective when a
-    process group of more than one rank exists."""
-    assert depth >= 1
+    process group of more than one rank exists.
+
+    every > 1 (reduced=True only): fewer, larger collectives -- the pairs of `every` consecutive steps go out in ONE all-reduce
+    issued after the last of them (the last group may be shorter).  The caller keeps the pairs in one int64[(depth + 2) * every, 2]
+    tensor, step i filling row i mod ((depth + 2) * every) and clearing the next one, and `group_view(first_step, n)` returns
+    the contiguous rows of steps first_step .. first_step + n - 1; `depth` then counts groups in flight and `consume(i, rows)`
+    is called once per group with the index of its last step.  What each collective costs the compute stream is the event
+    record / stream wait pair around it (ProcessGroupNCCL's ordering), not its 16 bytes: bench.py's emulated-collective table."""
+    assert depth >= 1 and every >= 1
+    assert every == 1 or (reduced and group_view is not None)
     from collections import deque
     out, pending = [], deque()
 
@@ -96,6 +104,11 @@ def pipelined_steps(step: Callable[[], torch.Tensor], steps: int, group=None, re
             buf = step()
         else:
             buf = local_pair(step())
+        if every > 1:
+            if i % every != every - 1 and i != steps - 1:
+                continue
+            first = i - i % every
+            buf = group_view(first, i - first + 1)
         pending.append((buf, issue(buf), i))
         if len(pending) > depth:
             retire()
