@@ -359,10 +359,21 @@ def secondary(device, rank):
     # Hessian-vector product (second-order backward), north-star shape
     prep = ops.Prepared(dev["labels"], dev["logits"], dev["label_length"], dev["logit_length"], 0, U=U)
     vec = torch.randn((B, T, V), device=device, generator=torch.Generator(device=device).manual_seed(0))
-    kms, wms = _events_ms(lambda: ops.hvp(ops.KINDS["classic"], _lib.WRT_LOGITS, prep, vec), 12, 3)
+    # (r04: warmed like the headline and timed over 40 calls -- 12 calls after 3 cold ones read 0.39-0.41 ms for a kernel that
+    # scripts/hvp_time.py measured at 0.32)
+    hvp_fn = lambda: ops.hvp(ops.KINDS["classic"], _lib.WRT_LOGITS, prep, vec)
+    prewarm(hvp_fn, 60.0)
+    kms, wms = _events_ms(hvp_fn, 40, 4)
+    hvp_traffic = None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_hvp_fused_pmc_traffic.json")) as f:
+            hvp_traffic = json.load(f).get("_total_bytes_per_call")
+    except Exception:
+        pass
     out["hvp"] = dict(workload=f"ctc_amd_hvp (Hessian-vector product, no [B,T,V,T,V] tensor) B={B} T={T} U={U} V={V}",
                       value=B / (wms * 1e-3), unit="utterances/s", ms_per_step=wms,
-                      roofline=_roof(B * 3 * T * V * 4, kms, traffic=None, note="algorithmic bytes: logits + vector read, product written"))
+                      roofline=_roof(B * 3 * T * V * 4, kms, traffic=hvp_traffic, note="algorithmic bytes: logits + vector read, product written; "
+                                     "traffic: profiles/r04_hvp_fused_pmc_traffic.json"))
     del vec, x
 
     # configs[4]: dense Hessian B=32 T=200 U=32 V=64

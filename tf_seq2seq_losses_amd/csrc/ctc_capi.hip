@@ -186,8 +186,9 @@ int ctc_amd_debug_override(const char *key, const char *value) {
     return CTC_AMD_OK;
   }
   if (!strcmp(key, "hvp")) {
-    if (!strncmp(value, "diag", 4) && value[4] >= '0' && value[4] <= '7' && !value[5]) {  // timing diagnostics (scripts/hvp_time.py)
-      ctc::g_hvp_diag = value[4] - '0';
+    int dm = 0;
+    if (!strncmp(value, "diag", 4) && sscanf(value + 4, "%d", &dm) == 1 && dm >= 0 && dm <= 31) {  // timing diagnostics (scripts/hvp_time.py)
+      ctc::g_hvp_diag = dm;
       ctc::g_force_hvp_v1 = 0;
       return CTC_AMD_OK;
     }

@@ -94,7 +94,14 @@ struct Lds {
 
 struct Geo {
   int len, G, tmb, tm, NB;
-  __device__ __forceinline__ void init(int len_) { len = len_; G = (len + BLK - 1) / BLK; tmb = G / 2; tm = tmb * BLK; NB = G - tmb; }
+  // NI1 / NI2: block iterations (= workgroup barriers) of phase 1 / phase 2, the same for every wavefront: NB + 1 / NB + 3 rounded
+  // up to the depth of the register rings of the wavefronts that load rows (4 / 3), so that their unrolled loops need no guard
+  // per slot (see estage1)
+  int NI1, NI2;
+  __device__ __forceinline__ void init(int len_) {
+    len = len_; G = (len + BLK - 1) / BLK; tmb = G / 2; tm = tmb * BLK; NB = G - tmb;
+    NI1 = (NB + 1 + 3) / 4 * 4; NI2 = (NB + 3 + 2) / 3 * 3;
+  }
   __device__ __forceinline__ int nvof(int g) const { int r = len - BLK * g; return r < BLK ? r : BLK; }
   __device__ __forceinline__ int nblocks(int phase, int side) const { return (phase == 1) == (side == 0) ? tmb : G - tmb; }
   __device__ __forceinline__ int absblock(int phase, int side, int j) const {
@@ -447,12 +454,17 @@ struct Rows {
   }
   // rows of frame t: logits (-inf beyond the vocabulary) and vector (0 beyond it); the address is clamped so that the load is
   // unconditional
+  // The loads are RAW: mask_xv is applied where the rows are consumed, iterations later.  (r03 masked inside the load: a select
+  // on a loaded register makes the compiler wait for the load on the spot -- s_waitcnt vmcnt(0) behind every pair of loads, so
+  // nothing was ever in flight ahead of its use and every row cost a full memory round trip: phase 1 took 136 us with its
+  // arithmetic switched off, for 524 MB that the same access pattern reads in 89 us -- scripts/r04_hbm_pattern.hip.)
   __device__ __forceinline__ void load_xv(float4 &x, float4 &v, int t) const {
     const int col = inrow ? lane * 4 : 0;
-    const float4 xr = *reinterpret_cast<const float4 *>(xbase + (long)t * Vr + col);
-    const float4 vr = *reinterpret_cast<const float4 *>(vbase + (long)t * Vr + col);
-    x = inrow ? xr : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    v = inrow ? vr : make_float4(0.f, 0.f, 0.f, 0.f);
+    x = *reinterpret_cast<const float4 *>(xbase + (long)t * Vr + col);
+    v = *reinterpret_cast<const float4 *>(vbase + (long)t * Vr + col);
+  }
+  __device__ __forceinline__ void mask_xv(float4 &x, float4 &v) const {
+    if (!inrow) { x = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); v = make_float4(0.f, 0.f, 0.f, 0.f); }
   }
   __device__ __forceinline__ float4 expo(const float4 &x, float mxl) const {
     return make_float4(fexp2(fmaf(x.x, LOG2E, -mxl)), fexp2(fmaf(x.y, LOG2E, -mxl)), fexp2(fmaf(x.z, LOG2E, -mxl)), fexp2(fmaf(x.w, LOG2E, -mxl)));
@@ -492,7 +504,8 @@ struct Rows {
   }
   // output row of frame t.  dqt[j]: tangent of the token posterior of slot j, dqb: of the blank posterior (this lane's part
   // already summed over the wave), both in units of 2^-30; asum = wave-wide sum of |dqt| (same units): no bin can exceed it.
-  __device__ __forceinline__ void out_row(int t, float dqb, const float (&dqt)[NL], float asum, const float4 &ev, const float4 &v, float inv, float svn) const {
+  // z = the softmax part s_t[k] (v_t[k] - s_t . v_t) of this lane's four columns.
+  __device__ __forceinline__ void out_row(int t, float dqb, const float (&dqt)[NL], float asum, const float4 &z) const {
     *reinterpret_cast<int4 *>(bins + lane * 4) = make_int4(0, 0, 0, 0);
     // fixed point: 2^28 units for the wave-wide sum of magnitudes (exact integer adds, any order)
     const int ea = (asum > 0.f) ? frexp_e(asum) : 0;
@@ -507,8 +520,7 @@ struct Rows {
     const float4 dq = make_float4(fmaf((float)pu.x, down, mb[0] * qb), fmaf((float)pu.y, down, mb[1] * qb),
                                   fmaf((float)pu.z, down, mb[2] * qb), fmaf((float)pu.w, down, mb[3] * qb));
     typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f r = {fmaf(ev.x * inv, v.x - svn, -dq.x), fmaf(ev.y * inv, v.y - svn, -dq.y), fmaf(ev.z * inv, v.z - svn, -dq.z),
-                   fmaf(ev.w * inv, v.w - svn, -dq.w)};
+    const v4f r = {z.x - dq.x, z.y - dq.y, z.z - dq.z, z.w - dq.w};
     if (inrow) __builtin_nontemporal_store(r, reinterpret_cast<v4f *>(obase + (long)t * Vr + lane * 4));
   }
 };
@@ -555,13 +567,11 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL> &S, Lds<KIND, NL> &
     const int j = it;
     if (j < nb) {
       const int g = geo.absblock(1, SIDE, j);
-      const int nv = geo.nvof(g);
+      const int nv = (lds.mode & 16) ? 0 : geo.nvof(g);  // (timing mode 16: the E stage of phase 1 keeps its loads and barriers only)
       float(*E)[Cfg<NL>::ES] = lds.E[SIDE][j % 3];
       float4 xq[NQ], vq[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) { xq[q] = xb[r][q]; vq[q] = vb[r][q]; }
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) S.load_xv(xb[r][q], vb[r][q], fr(j + PFD, P0 + q));  // refill the slot: PFD blocks ahead
+      for (int q = 0; q < NQ; ++q) { xq[q] = xb[r][q]; vq[q] = vb[r][q]; S.mask_xv(xq[q], vq[q]); }
       float prod = 1.f;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
@@ -583,12 +593,22 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL> &S, Lds<KIND, NL> &
       }
       acc += (double)flog2(prod);
     }
+    // Refill the slot, PFD blocks ahead.  (a) AFTER its rows have been used: issued before, old and new rows were alive together,
+    // the slot changed registers every iteration and the copy back at the end of the iteration waited for the loads just issued.
+    // (b) On EVERY path (the index is clamped, the load is always legal), in a loop without a guard per slot (Geo::NI1): the
+    // s_waitcnt in front of a slot's use is a COUNT of younger loads that may stay in flight, fixed at compile time -- with a
+    // path on which the younger refills are skipped (the tail: j >= nb) that count is 0, on every iteration.  r03 had both:
+    // s_waitcnt vmcnt(0) behind each load, nothing ever in flight across an iteration, 136 us for a phase 1 whose loads take 89.
+#ifdef CTC_HVPF_DIAG_NOLOAD
+    if (!(lds.mode & 16))
+#endif
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) S.load_xv(xb[r][q], vb[r][q], fr(j + PFD, P0 + q));
     block_barrier_raw();
   };
-  for (int it0 = 0; it0 <= geo.NB; it0 += PFD) {
-    static_for<0, PFD>([&](auto R) {
-      if (it0 + decltype(R)::value <= geo.NB) body(R, it0 + decltype(R)::value);
-    });
+  static_assert(PFD == 4, "Geo::NI1 is rounded to this ring depth");
+  for (int it0 = 0; it0 < geo.NI1; it0 += PFD) {
+    static_for<0, PFD>([&](auto R) { body(R, it0 + decltype(R)::value); });
   }
   bool bad = !(zb >= EMIS_MIN) || !(acc - acc == 0.0);
 #pragma unroll
@@ -623,7 +643,7 @@ __device__ __forceinline__ void run_main(const Problem &p, float *__restrict__ r
   // ================= phase 1 =================
   {
     const int nb = geo.nblocks(1, DIR);
-    for (int it = 0; it <= geo.NB; ++it) {
+    for (int it = 0; it < geo.NI1; ++it) {
       const int j = it - 1;
       if (j >= 0 && j < nb) {
         const int g = geo.absblock(1, DIR, j);
@@ -634,6 +654,7 @@ __device__ __forceinline__ void run_main(const Problem &p, float *__restrict__ r
           // the emission rows of the whole block go to registers first: the sequential chain never waits for an LDS round trip
           Emis<NL> eb[BLK];
           static_for<0, BLK>([&](auto D) { read_E<NL>(E[decltype(D)::value], lane, eb[decltype(D)::value]); });
+          if (!(lds.mode & 8))
           static_for<0, BLK>([&](auto D) {
             constexpr int d = decltype(D)::value;
             S.step(eb[d]);
@@ -715,7 +736,7 @@ __device__ __forceinline__ void run_main(const Problem &p, float *__restrict__ r
   {
     const int nb = geo.nblocks(2, DIR);
     int kflag = 0;
-    for (int it = 0; it <= geo.NB + 2; ++it) {
+    for (int it = 0; it < geo.NI2; ++it) {
       const int j = it - 2;
       if (j >= 0 && j < nb && !idle) {
         const int g = geo.absblock(2, DIR, j);
@@ -888,7 +909,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const float *__r
   };
   CkRow<NL> ck_next;
   load_ck<NL>(ck_next, ck_rows, ck_k, ck_slot(0), lane);
-  for (int it = 0; it <= geo.NB + 2; ++it) {
+  for (int it = 0; it < geo.NI2; ++it) {
     const int j = it - 1;
     if (j >= 0 && j < nb && !idle) {
       const int g = geo.absblock(2, SIDE, j);
@@ -989,32 +1010,39 @@ __device__ __forceinline__ void run_helper(const Problem &p, float4 *__restrict_
     t = t < len ? t : len - 1;
     return t < 0 ? 0 : t;
   };
-  // Two register rings addressed at compile time (the loop is unrolled by 2): E-stage rows loaded 2 blocks ahead, G-stage rows
-  // (the same rows, needed again three blocks later: read once more, mostly from L2) loaded ONE iteration ahead -- loaded at the
-  // top of the iteration that uses them they cost the helpers ~1.5 us of waiting per block.
-  constexpr int PF2 = 2;
+  // Register rings addressed at compile time (the loop is unrolled by 3).  X / Vv / SX: the rows of block it + 3, loaded while
+  // block it is worked on (an HBM load under load takes ~2 us, a block ~1 us), with the frame's (rowmax, 1 / sum, s.v / sum).
+  // Z: the softmax part of the output row of block it, s_t[k] (v_t[k] - s_t . v_t), computed by its E stage and kept for its G
+  // stage three iterations later (out = Z - d posterior) -- r03 read logits and vector rows again there (mostly past the L2: 0.5 GB
+  // of the call's 2.0 GB of fabric traffic) and exponentiated again.
+  constexpr int PF2 = 3;
   float4 X[PF2][N2], Vv[PF2][N2];
-  float SX[PF2][N2];
-  float4 XG[2][N2], VG[2][N2], SG[2][N2];
+  float SX[PF2][N2], SI[PF2][N2], SV[PF2][N2];
+  float4 Z[3][N2];
+  auto load_st = [&](int r_, int q, int t) __attribute__((always_inline)) {
+    const float4 st = stats[t];
+    SX[r_][q] = st.x; SI[r_][q] = st.y; SV[r_][q] = st.z;
+  };
   static_for<0, PF2>([&](auto R) {
     constexpr int r = decltype(R)::value;
 #pragma unroll
     for (int q = 0; q < N2; ++q) {
-      X[r][q] = make_float4(0.f, 0.f, 0.f, 0.f); Vv[r][q] = X[r][q]; SX[r][q] = 0.f;
-      XG[r][q] = X[r][q]; VG[r][q] = X[r][q]; SG[r][q] = X[r][q];
-      if (nb > 0) { S.load_xv(X[r][q], Vv[r][q], fr(r, P2 + q)); SX[r][q] = stats[fr(r, P2 + q)].x; }
+      X[r][q] = make_float4(0.f, 0.f, 0.f, 0.f); Vv[r][q] = X[r][q]; SX[r][q] = 0.f; SI[r][q] = 0.f; SV[r][q] = 0.f;
+      Z[r][q] = X[r][q];
+      if (nb > 0) { S.load_xv(X[r][q], Vv[r][q], fr(r, P2 + q)); load_st(r, q, fr(r, P2 + q)); }
     }
   });
   bool massbad = false;
   const bool idle = (lds.mode & 4) != 0;
   auto body = [&](auto R, int it) __attribute__((always_inline)) {
-    constexpr int r = decltype(R)::value;  // = it mod 2
+    constexpr int r = decltype(R)::value;  // = it mod 3
     if (idle) { block_barrier_raw(); return; }
     const int gj = it - 3;
     const bool do_g = gj >= 0 && gj < nb;
-    // rows of the NEXT iteration's G block (block it-2) into the other set
+    // what this iteration's G stage (block it-3) works on: kept by that block's E stage in this very ring slot
+    float4 zg[N2];
 #pragma unroll
-    for (int q = 0; q < N2; ++q) { S.load_xv(XG[1 - r][q], VG[1 - r][q], fr(gj + 1, P2 + q)); SG[1 - r][q] = stats[fr(gj + 1, P2 + q)]; }
+    for (int q = 0; q < N2; ++q) zg[q] = Z[r][q];
     // ---- E stage (block it) ----
     const int j = it;
     if (j < nb) {
@@ -1022,11 +1050,9 @@ __device__ __forceinline__ void run_helper(const Problem &p, float4 *__restrict_
       const int nv = geo.nvof(g);
       float(*E)[C::ES] = lds.E[DIR][j % 3];
       float4 xq[N2], vq[N2];
-      float sq[N2];
+      float sq[N2], si[N2], sv[N2];
 #pragma unroll
-      for (int q = 0; q < N2; ++q) { xq[q] = X[r][q]; vq[q] = Vv[r][q]; sq[q] = SX[r][q]; }
-#pragma unroll
-      for (int q = 0; q < N2; ++q) { S.load_xv(X[r][q], Vv[r][q], fr(j + PF2, P2 + q)); SX[r][q] = stats[fr(j + PF2, P2 + q)].x; }
+      for (int q = 0; q < N2; ++q) { xq[q] = X[r][q]; vq[q] = Vv[r][q]; S.mask_xv(xq[q], vq[q]); sq[q] = SX[r][q]; si[q] = SI[r][q]; sv[q] = SV[r][q]; }
 #pragma unroll
       for (int q = 0; q < N2; ++q) {
         const int d = P2 + q;
@@ -1035,9 +1061,14 @@ __device__ __forceinline__ void run_helper(const Problem &p, float4 *__restrict_
           Emis<NL> e;
           S.gather(ev, vq[q], e);
           write_E<NL>(E[d], dump, lane, e);
+          Z[r][q] = make_float4(ev.x * si[q] * (vq[q].x - sv[q]), ev.y * si[q] * (vq[q].y - sv[q]), ev.z * si[q] * (vq[q].z - sv[q]),
+                                ev.w * si[q] * (vq[q].w - sv[q]));
         }
       }
     }
+    // (refill after use and on every path, as in phase 1)
+#pragma unroll
+    for (int q = 0; q < N2; ++q) { S.load_xv(X[r][q], Vv[r][q], fr(j + PF2, P2 + q)); load_st(r, q, fr(j + PF2, P2 + q)); }
     // ---- G stage (block it-3) ----
     if (do_g) {
       const int g = geo.absblock(2, DIR, gj);
@@ -1077,18 +1108,14 @@ __device__ __forceinline__ void run_helper(const Problem &p, float4 *__restrict_
         const int d = P2 + q;
         if (d < nv) {
           massbad |= !(fabsf(readlane_f(qall, SwapLanes<4>::lane(q)) - 1073741824.0f) < 1073741824.0f * MASS_TOL);  // D6
-          const float4 ev = S.expo(XG[r][q], SG[r][q].x);
-          S.out_row(geo.frame(DIR, g, d), readlane_f(dball, SwapLanes<4>::lane(q)), dqt[q], readlane_f(aall, SwapLanes<4>::lane(q)), ev, VG[r][q],
-                    SG[r][q].y, SG[r][q].z);
+          S.out_row(geo.frame(DIR, g, d), readlane_f(dball, SwapLanes<4>::lane(q)), dqt[q], readlane_f(aall, SwapLanes<4>::lane(q)), zg[q]);
         }
       }
     }
     block_barrier_raw();
   };
-  for (int it0 = 0; it0 <= geo.NB + 2; it0 += 2) {
-    static_for<0, 2>([&](auto R) {
-      if (it0 + decltype(R)::value <= geo.NB + 2) body(R, it0 + decltype(R)::value);
-    });
+  for (int it0 = 0; it0 < geo.NI2; it0 += 3) {
+    static_for<0, 3>([&](auto R) { body(R, it0 + decltype(R)::value); });
   }
   if (massbad && lane == 0) atomicOr(&lds.flag, 64);  // D6
   __syncthreads();
@@ -1132,7 +1159,8 @@ __global__ __launch_bounds__(64 * NW) void hvp_fused_kernel(Problem p, Layout L,
                                                              const float *__restrict__ vec, float *__restrict__ out,
                                                              int *__restrict__ flag_ws, int mode) {
   // mode (timing diagnostics through ctc_amd_debug_override("hvp", "diag<mode>"), 0 in every product call): 1 = stop at the meeting
-  // point, 2 = the chains keep only their barriers in phase 2, 4 = the helpers do
+  // point, 2 = the chains keep only their barriers in phase 2, 4 = the helpers do, 8 = the main chains in phase 1, 16 = the E stage
+  // of phase 1 keeps its loads and barriers only
   __shared__ __attribute__((aligned(16))) Lds<KIND, NL> lds;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x;
@@ -1143,36 +1171,44 @@ __global__ __launch_bounds__(64 * NW) void hvp_fused_kernel(Problem p, Layout L,
   __syncthreads();
   // Wavefronts w, w + 4, w + 8 share a SIMD (0 and 1 hold three, 2 and 3 two): the main chains -- the busiest wavefronts -- sit on
   // the two-wavefront SIMDs with one helper each, the recompute chains with two helpers each.
-  if (w == 2) {
+  // (CTC_HVPF_PROBE_ROLE, diagnostic builds: compile ONE role only, to read its register need off -Rpass-analysis=kernel-resource-usage)
+#ifndef CTC_HVPF_PROBE_ROLE
+#define CTC_HVPF_PROBE_ROLE -1
+#endif
+  constexpr int PR = CTC_HVPF_PROBE_ROLE;
+  auto is = [&](int role) { return (PR < 0 || PR == role) && w == role; };
+  if (is(2)) {
     __builtin_amdgcn_s_setprio(3);
     run_main<KIND, NL, 0>(p, rows_ws, kexp_ws, nslot, loss, flag_ws, lds, geo, b);
-  } else if (w == 3) {
+  } else if (is(3)) {
     __builtin_amdgcn_s_setprio(3);
     run_main<KIND, NL, 1>(p, rows_ws, kexp_ws, nslot, loss, flag_ws, lds, geo, b);
-  } else if (w == 0) {
+  } else if (is(0)) {
     __builtin_amdgcn_s_setprio(2);
     run_recompute<KIND, NL, 0>(p, rows_ws, kexp_ws, nslot, stats_ws, vec, lds, geo, b);
-  } else if (w == 1) {
+  } else if (is(1)) {
     __builtin_amdgcn_s_setprio(2);
     run_recompute<KIND, NL, 1>(p, rows_ws, kexp_ws, nslot, stats_ws, vec, lds, geo, b);
-  } else if (w == 4) {
+  } else if (is(4)) {
     run_helper<KIND, NL, 0, 0, 2, 0, 2>(p, stats_ws, vec, out, lds, geo, 0, b);
-  } else if (w == 5) {
+  } else if (is(5)) {
     run_helper<KIND, NL, 1, 0, 2, 0, 2>(p, stats_ws, vec, out, lds, geo, 0, b);
-  } else if (w == 6) {
+  } else if (is(6)) {
     run_helper<KIND, NL, 0, 2, 2, 2, 2>(p, stats_ws, vec, out, lds, geo, 1, b);
-  } else if (w == 7) {
+  } else if (is(7)) {
     run_helper<KIND, NL, 1, 2, 2, 2, 2>(p, stats_ws, vec, out, lds, geo, 1, b);
-  } else if (w == 8) {
+  } else if (is(8)) {
     run_helper<KIND, NL, 0, 4, 1, 4, 2>(p, stats_ws, vec, out, lds, geo, 2, b);
-  } else {
+  } else if (is(9)) {
     run_helper<KIND, NL, 1, 4, 1, 4, 2>(p, stats_ws, vec, out, lds, geo, 2, b);
   }
   // utterances the linear domain cannot hold (normally none): redone right here in the log domain, every output row rewritten
   __syncthreads();
   const int fl = lds.mode ? 0 : lds.flag;
   __syncthreads();  // (the LDS is reused from here on)
-  if (fl != 0) redo_log_domain<KIND, NL>(p, L, ws_v1, vec, loss, out, reinterpret_cast<float *>(&lds), w, b);
+#ifndef CTC_HVPF_NO_REDO
+  if (PR < 0 && fl != 0) redo_log_domain<KIND, NL>(p, L, ws_v1, vec, loss, out, reinterpret_cast<float *>(&lds), w, b);
+#endif
 }
 
 }  // namespace hvpf
