@@ -28,13 +28,19 @@ for lib in libs:  # (diagnostic builds carry extra workspace regions: the larges
     need = max(need, nbytes.value)
 nbytes = ctypes.c_size_t(need)
 ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-loss = torch.empty(B, device=dev); grad = torch.empty(B, T, V, device=dev)
+loss = torch.empty(B, device=dev)
+NROT = int(os.environ.get("AB_ROTATE", "1"))  # > 1: that many logits / gradient buffer sets in rotation (nothing of a call's rows is cached)
+xs = [d["logits"]] + [d["logits"].clone() for _ in range(NROT - 1)]
+grads = [torch.empty(B, T, V, device=dev) for _ in range(NROT)]
 stream = torch.cuda.current_stream().cuda_stream
+ncall = [0]
 
 
 def call(lib):
-    rc = lib.ctc_amd_loss_grad(kind, 0, d["logits"].data_ptr(), d["labels"].data_ptr(), d["labels"].shape[1], d["label_length"].data_ptr(),
-                               d["logit_length"].data_ptr(), 0, B, T, V, U, loss.data_ptr(), grad.data_ptr(), None, ws.data_ptr(), nbytes.value, stream)
+    k = ncall[0] % NROT
+    ncall[0] += 1
+    rc = lib.ctc_amd_loss_grad(kind, 0, xs[k].data_ptr(), d["labels"].data_ptr(), d["labels"].shape[1], d["label_length"].data_ptr(),
+                               d["logit_length"].data_ptr(), 0, B, T, V, U, loss.data_ptr(), grads[k].data_ptr(), None, ws.data_ptr(), nbytes.value, stream)
     assert rc == 0, lib.ctc_amd_last_error()
 
 

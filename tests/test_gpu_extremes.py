@@ -52,7 +52,9 @@ def test_long_utterances(kind):
     The log-domain kernel, which redoes utterances the linear one flags, carries ~4e-6 of ABSOLUTE rounding per step on
     renormalised logarithms of magnitude ~100: r02 measured 1.34e-3 at this length (2.4e-4 at T = 1000).  Since r03 its posteriors are
     normalised by the frame's own mass, which divides the common part of that rounding out: measured 1.9e-4 here (classic; 2.4e-5
-    simplified) and 4.3e-5 at T = 1000, bound 3e-4; the loss (offsets in double) keeps its 1e-4 relative bound on both."""
+    simplified) and 4.3e-5 at T = 1000.  What was left is the float32 log-sum-exp chain of the sweep itself (a host-side model with
+    a float64 chain and the SAME float32 emissions: 9e-7); since r04 the log-domain roles keep their lattice state in float64
+    (ctc_common.h lse2, rows stay float32) and hold north_star's 1e-4 here too; the loss keeps its 1e-4 relative bound on both."""
     rng = np.random.default_rng(2)
     B, T, V, U = 3, 5000, 256, 128
     logits = rng.standard_normal((B, T, V)).astype(np.float32)
@@ -62,7 +64,7 @@ def test_long_utterances(kind):
     from tf_seq2seq_losses_amd import _lib
     _lib.debug_override("pipeline", "fused5")
     try:
-        _check(kind, logits, labels, ll, tl, tol_g=3e-4)
+        _check(kind, logits, labels, ll, tl, tol_g=1e-4)
     finally:
         _lib.debug_override("pipeline", "")
 

@@ -120,7 +120,7 @@ def test_backward_never_writes_the_returned_loss(kind):
     assert torch.equal(before, loss.detach()) and loss._version == ver
     rl, rg = C.loss_grad(kind, labels, logits, ll, tl, 0)
     assert (np.abs(before.cpu().numpy() - rl) / np.abs(rl)).max() < TOL
-    assert np.abs(g.cpu().numpy() - rg).max() < 2e-4  # (utterances redone in the log domain: that kernel's accuracy at T = 600, sharp logits)
+    assert np.abs(g.cpu().numpy() - rg).max() < 1e-4  # (r03: 2e-4 for the utterances redone in the log domain)
     assert np.abs(g.cpu().numpy()[:2] - rg[:2]).max() < 1e-5  # benign ones: the linear kernel's
 
 

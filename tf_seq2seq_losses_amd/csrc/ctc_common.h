@@ -68,6 +68,15 @@ __device__ __forceinline__ float lse2(float a, float b) {
   return fmaxf(a, b) + flog2(1.0f + fexp2(-fabsf(a - b)));  // |.| and the negation are free source modifiers
 }
 
+// The same on a float64 state (the log-domain roles of the fused tiers since r04: the sweep's log-sum-exp chain is what carries
+// their error -- host-side model scratch-free in DESIGN.md section 2: float32 chain 2e-5 ... 8e-5 of posterior error at T = 1000
+// with N(0, 4^2) logits, float64 chain 9e-7 with the SAME float32 emissions; the transcendental part stays float32: its argument
+// is a difference, its result lies in [0, 1]).  gfx950 issues v_add_f64 / v_max_f64 at the float32 rate.
+__device__ __forceinline__ double lse2(double a, double b) {
+  const float d = (float)(a - b);
+  return fmax(a, b) + (double)flog2(1.0f + fexp2(-fabsf(d)));
+}
+
 // lane i receives x from lane i-1; lane 0 receives `fill` (DPP wave_shr:1, one VALU op, no LDS).
 __device__ __forceinline__ float from_prev_lane(float x, float fill) {
   int v = __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x138, 0xf, 0xf, false);
@@ -77,6 +86,18 @@ __device__ __forceinline__ float from_prev_lane(float x, float fill) {
 __device__ __forceinline__ float from_next_lane(float x, float fill) {
   int v = __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x130, 0xf, 0xf, false);
   return __int_as_float(v);
+}
+
+// (float64: the two halves travel separately)
+__device__ __forceinline__ double from_prev_lane(double x, double fill) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(x), 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(x), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_next_lane(double x, double fill) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(x), 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(x), 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
 
 // Lanes of ONE wavefront exchanging data through LDS (scatter by one lane, read by another): the hardware executes the

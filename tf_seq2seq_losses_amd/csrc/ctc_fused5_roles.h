@@ -157,14 +157,14 @@ __device__ __forceinline__ void state_row(const S_t &S, float (&cs)[NL], float4 
   float tx;
   if constexpr (DIR == 0) {
 #pragma unroll
-    for (int j = NL - 1; j > 0; --j) cs[j] = S.c[j - 1];
-    cs[0] = from_prev_lane(S.c[NL - 1], S.cx);
-    tx = readlane_f(S.c[NL - 1], 63);
+    for (int j = NL - 1; j > 0; --j) cs[j] = (float)S.c[j - 1];
+    cs[0] = from_prev_lane((float)S.c[NL - 1], (float)S.cx);
+    tx = readlane_f((float)S.c[NL - 1], 63);
   } else {
 #pragma unroll
-    for (int j = 0; j < NL - 1; ++j) cs[j] = S.c[j + 1];
-    cs[NL - 1] = from_next_lane(S.c[0], S.cx);
-    tx = readlane_f(S.c[0], 0);
+    for (int j = 0; j < NL - 1; ++j) cs[j] = (float)S.c[j + 1];
+    cs[NL - 1] = from_next_lane((float)S.c[0], (float)S.cx);
+    tx = readlane_f((float)S.c[0], 0);
   }
   const float oh = (float)S.off;
   tail = make_float4(tx, 0.f, oh, (float)(S.off - (double)oh));
@@ -331,7 +331,7 @@ __device__ __forceinline__ void run_main(const Problem &p, const Layout &L, floa
                                          float *__restrict__ beta_ws, double *__restrict__ logp_ws,
                                          float *__restrict__ loss, Lds<KIND, NL, NH, BLK, VPL> &lds, const Geo<BLK> &geo,
                                          void *stamp_ws, bool want_grad, int b) {
-  using S_t = Side<KIND, NL, VPL, DIR, true>;
+  using S_t = Side<KIND, NL, VPL, DIR, true, 0, double>;  // (float64 lattice state: ctc_common.h lse2)
   using LD = Lds<KIND, NL, NH, BLK, VPL>;
   S_t S;
   const int lane = threadIdx.x & 63;
@@ -473,7 +473,7 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
                                               Lds<KIND, NL, NH, BLK, VPL> &lds, const Geo<BLK> &geo, void *stamp_ws,
                                               bool want_grad, int b) {
   constexpr int RDIR = 1 - SIDE;  // direction of the recursion this wave runs
-  using S_t = Side<KIND, NL, VPL, RDIR, true, XT>;
+  using S_t = Side<KIND, NL, VPL, RDIR, true, XT, double>;
   using LD = Lds<KIND, NL, NH, BLK, VPL>;
   S_t S;
   const int lane = threadIdx.x & 63;
@@ -528,10 +528,12 @@ __device__ __forceinline__ void run_recompute(const Problem &p, const Layout &L,
       load_srow<KIND, NL>(ck_next, ck_rows + (long)ck_index(j + 1) * L.SRS, lane, UP);  // next block's checkpoint, a block ahead
       restore_state<KIND, NL, RDIR>(S, ck);
       auto put = [&](int d) __attribute__((always_inline)) {
-        float cs[NL];
+        float cs[NL], os[NL];
         float4 tail;
         state_row<KIND, NL, RDIR>(S, cs, tail);
-        write_R<KIND, NL, LD>(RR[d], dump, lane, cs, S.o, tail);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) os[j] = (float)S.o[j];
+        write_R<KIND, NL, LD>(RR[d], dump, lane, cs, os, tail);
       };
       auto stp = [&](int d) __attribute__((always_inline)) {
         Emis<NL> e;

@@ -872,6 +872,9 @@ template <int BLK, int NH, int NL>
 struct P1Split {
   // (NH = 1, the 3-frame blocks of the 8-positions-per-lane variant: two frames for the helper, one for the recompute wavefront;
   // NH = 6, sixteen wavefronts: two frames for every helper, none for the recompute wavefronts)
+  // (NH = 3 for the six-frame blocks of the four-positions-per-lane variant -- 2, 2, 1 frames for the helpers, 1 for the recompute
+  // wavefront -- was built and measured in r04: 227 us against 211 at U = 256: those shapes are bound by their chains, and more
+  // helpers only take issue slots from them)
   static constexpr int X = NH == 6 ? BLK / 6 : NH == 4 ? CTC_F6_X : NH == 2 ? BLK / 3 : 2, Y = NH == 6 ? BLK / 6 : NH == 4 ? CTC_F6_Y : NH == 2 ? BLK / 3 : 0;
   static constexpr int R = NH == 6 ? 0 : NH == 4 ? BLK - 2 * X - 2 * Y : NH == 2 ? BLK - X - Y : BLK - X;
   static_assert(NH == 6 || NH == 4 || NH == 2 || NH == 1, "helpers per side");
@@ -2055,7 +2058,11 @@ hipError_t CTC_F6_ENTRY(const Problem &p, const Layout &L, char *ws, float *loss
   }
 #if defined(CTC_F6_NS_ONLY)
   if (p.V > 256) return hipErrorInvalidValue;
-  return launch6<CTC_FUSED6_NL, CTC_F6_NH12, 12, 1>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st);
+#ifndef CTC_F6_NS_NH
+#define CTC_F6_NS_NH CTC_F6_NH12
+#define CTC_F6_NS_BLK 12
+#endif
+  return launch6<CTC_FUSED6_NL, CTC_F6_NS_NH, CTC_F6_NS_BLK, 1>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st);
 #elif CTC_FUSED6_NL == 8
   return p.V <= 256 ? launch6<8, 1, 3, 1>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st)
                     : launch6<8, 1, 3, 2>(p, L, alpha, beta, kexp, logp, stats, sink, loss, d_loss, grad, flags, meet, perm, st);

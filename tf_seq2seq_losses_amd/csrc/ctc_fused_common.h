@@ -29,6 +29,9 @@ constexpr int NPACE = 48; // pacing stores after a ring prologue (see Side::pace
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // (wave64 DPP reductions wave_sum_dpp / wave_max_dpp: ctc_common.h)
+__device__ __forceinline__ double readlane_f(double v, int l) {  // (float64 state of the log-domain roles: the two halves)
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
@@ -128,11 +131,13 @@ struct Emis {
 // XT: format of logits and gradient in HBM: 0 = contiguous float32 (frame stride V folded into the addressing),
 // 1 = float32 with run-time frame strides, 2 = bfloat16 with run-time frame strides, 3 = float32, any vocabulary size
 // and stride (rows not 16-byte aligned: element-wise loads and stores).  Arithmetic is float32 either way.
-template <int KIND, int NL, int VPL, int DIR, bool LOGITS, int XT = 0>
+// ST: type of the lattice state.  float32 (the Hessian's scans); float64 in the log-domain roles of the fused tiers since r04 --
+// rows in LDS and HBM stay float32 (one rounding where a state is written out, none accumulated along the sweep).
+template <int KIND, int NL, int VPL, int DIR, bool LOGITS, int XT = 0, class ST = float>
 struct Side {
   static constexpr int V = 256 * VPL;
   // lattice state
-  float c[NL], o[NL], cx;
+  ST c[NL], o[NL], cx;
   double off;
   bool norep[NL], norep_next[NL];
   int tokoff[NL];  // byte offset of label[i] inside the LDS copy of the logits row (pad slot for i >= label_length)
@@ -321,22 +326,22 @@ struct Side {
   __device__ __forceinline__ void step(const Emis<NL> &e) {
     const float bl = e.bl;
     if constexpr (KIND == 0 && DIR == 0) {
-      float m[NL], x[NL];
+      ST m[NL], x[NL];
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
         m[j] = lse2(c[j], o[j]);
         x[j] = norep_next[j] ? m[j] : c[j];
       }
-      float xin0 = from_prev_lane(x[NL - 1], cx);
+      ST xin0 = from_prev_lane(x[NL - 1], cx);
 #pragma unroll
       for (int j = NL - 1; j >= 0; --j) {
-        float xin = (j == 0) ? xin0 : x[j - 1];
+        ST xin = (j == 0) ? xin0 : x[j - 1];
         o[j] = e.y[j] + lse2(o[j], xin);
         c[j] = bl + m[j];
       }
       cx += bl;
     } else if constexpr (KIND == 0 && DIR == 1) {
-      float h[NL], ee[NL], pn[NL], x[NL];
+      ST h[NL], ee[NL], pn[NL], x[NL];
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
         h[j] = bl + c[j];
@@ -345,26 +350,26 @@ struct Side {
         x[j] = norep[j] ? pn[j] : h[j];
       }
       cx += bl;
-      float xinl = from_next_lane(x[0], cx);
+      ST xinl = from_next_lane(x[0], cx);
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
-        float xin = (j == NL - 1) ? xinl : x[j + 1];
+        ST xin = (j == NL - 1) ? xinl : x[j + 1];
         o[j] = lse2(xin, ee[j]);
         c[j] = pn[j];
       }
     } else if constexpr (KIND == 1 && DIR == 0) {
-      float pin0 = from_prev_lane(c[NL - 1], cx);
+      ST pin0 = from_prev_lane(c[NL - 1], cx);
 #pragma unroll
       for (int j = NL - 1; j >= 0; --j) {
-        float pin = (j == 0) ? pin0 : c[j - 1];
+        ST pin = (j == 0) ? pin0 : c[j - 1];
         c[j] = lse2(bl + c[j], e.y[j] + pin);
       }
       cx += bl;
     } else {
-      float nin = from_next_lane(c[0], cx);
+      ST nin = from_next_lane(c[0], cx);
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
-        float nx = (j == NL - 1) ? nin : c[j + 1];
+        ST nx = (j == NL - 1) ? nin : c[j + 1];
         c[j] = lse2(bl + c[j], e.y[j] + nx);
       }
       cx += bl;
@@ -372,11 +377,11 @@ struct Side {
   }
 
   __device__ __forceinline__ void renorm() {
-    float mx = cx;
+    float mx = (float)cx;  // (any common shift will do: the float32 image of the maximum, subtracted as it is)
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      mx = fmaxf(mx, c[j]);
-      if constexpr (KIND == 0) mx = fmaxf(mx, o[j]);
+      mx = fmaxf(mx, (float)c[j]);
+      if constexpr (KIND == 0) mx = fmaxf(mx, (float)o[j]);
     }
     mx = wave_max_dpp(mx);
     mx = (mx > NEG_THR) ? mx : 0.f;
@@ -391,39 +396,41 @@ struct Side {
 
   // spill the current state as lattice row `t` in the layout the other side is aligned with
   __device__ __forceinline__ void spill(int t, float smx, float sl2s) const {
-    float cs[NL];
+    float cs[NL], os[NL];  // (rows are float32 whatever the state type)
     float tx;
     if constexpr (DIR == 0) {  // slot i <- state_c(l=i): previous slot's c; tail <- state_c(l=UP): last slot's c
 #pragma unroll
-      for (int j = NL - 1; j > 0; --j) cs[j] = c[j - 1];
-      cs[0] = from_prev_lane(c[NL - 1], cx);
-      tx = readlane_f(c[NL - 1], 63);
+      for (int j = NL - 1; j > 0; --j) cs[j] = (float)c[j - 1];
+      cs[0] = from_prev_lane((float)c[NL - 1], (float)cx);
+      tx = readlane_f((float)c[NL - 1], 63);
     } else {  // slot i <- state_c(l=i+1): next slot's c; tail <- state_c(l=0): first slot's c
 #pragma unroll
-      for (int j = 0; j < NL - 1; ++j) cs[j] = c[j + 1];
-      cs[NL - 1] = from_next_lane(c[0], cx);
-      tx = readlane_f(c[0], 0);
+      for (int j = 0; j < NL - 1; ++j) cs[j] = (float)c[j + 1];
+      cs[NL - 1] = from_next_lane((float)c[0], (float)cx);
+      tx = readlane_f((float)c[0], 0);
     }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) os[j] = (float)o[j];
     const float oh = (float)off;
-    store_srow<KIND, NL>(own_rows + (long)t * SRS, lane, UP, cs, o, make_float4(tx, 0.f, oh, (float)(off - (double)oh)),
+    store_srow<KIND, NL>(own_rows + (long)t * SRS, lane, UP, cs, os, make_float4(tx, 0.f, oh, (float)(off - (double)oh)),
                          make_float2(smx, sl2s));
   }
 
   // log2 P at the meeting point from this side's state and the other side's row of the same time index
   __device__ __forceinline__ double meet(const SRow<KIND, NL> &r) const {
-    float v[2 * NL + 1];
-    float m = cx + r.tail.x;
+    ST v[2 * NL + 1];
+    float m = (float)(cx + r.tail.x);
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       v[2 * j] = c[j] + r.a[j];
-      v[2 * j + 1] = (KIND == 0) ? o[j] + r.b[j] : NEG;
-      m = fmaxf(m, fmaxf(v[2 * j], v[2 * j + 1]));
+      v[2 * j + 1] = (KIND == 0) ? o[j] + r.b[j] : (ST)NEG;
+      m = fmaxf(m, fmaxf((float)v[2 * j], (float)v[2 * j + 1]));
     }
     m = wave_max_dpp(m);
     if (!(m > NEG_THR)) return -INFINITY;
-    float s = (lane == 0) ? fexp2(cx + r.tail.x - m) : 0.f;
+    float s = (lane == 0) ? fexp2((float)(cx + r.tail.x - m)) : 0.f;
 #pragma unroll
-    for (int j = 0; j < 2 * NL; ++j) s += fexp2(v[j] - m);
+    for (int j = 0; j < 2 * NL; ++j) s += fexp2((float)(v[j] - m));
     s = wave_sum_dpp(s);
     return (double)m + (double)flog2(s) + off + (double)r.tail.z + (double)r.tail.w;
   }
@@ -552,26 +559,26 @@ struct Side {
     if constexpr (KIND == 0 && DIR == 0) step(e);
     if constexpr (KIND == 0) {
 #pragma unroll
-      for (int j = 0; j < NL; ++j) { s1[j] = c[j] + r.a[j] + sc; s2[j] = o[j] + r.b[j] + sc; }
-      s0 = cx + r.tail.x + sc;
+      for (int j = 0; j < NL; ++j) { s1[j] = (float)(c[j] + r.a[j] + sc); s2[j] = (float)(o[j] + r.b[j] + sc); }
+      s0 = (float)(cx + r.tail.x + sc);
     } else if constexpr (DIR == 0) {
-      float pin0 = from_prev_lane(c[NL - 1], cx);
+      ST pin0 = from_prev_lane(c[NL - 1], cx);
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
-        float pin = (j == 0) ? pin0 : c[j - 1];
-        s1[j] = c[j] + e.bl + r.a[j] + sc;
-        s2[j] = pin + e.y[j] + r.a[j] + sc;
+        ST pin = (j == 0) ? pin0 : c[j - 1];
+        s1[j] = (float)(c[j] + e.bl + r.a[j] + sc);
+        s2[j] = (float)(pin + e.y[j] + r.a[j] + sc);
       }
-      s0 = cx + e.bl + r.tail.x + sc;
+      s0 = (float)(cx + e.bl + r.tail.x + sc);
     } else {
-      float nin = from_next_lane(c[0], cx);
+      ST nin = from_next_lane(c[0], cx);
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
-        float nx = (j == NL - 1) ? nin : c[j + 1];
-        s1[j] = c[j] + e.bl + r.a[j] + sc;
-        s2[j] = r.a[j] + e.y[j] + nx + sc;
+        ST nx = (j == NL - 1) ? nin : c[j + 1];
+        s1[j] = (float)(c[j] + e.bl + r.a[j] + sc);
+        s2[j] = (float)(r.a[j] + e.y[j] + nx + sc);
       }
-      s0 = cx + e.bl + r.tail.x + sc;
+      s0 = (float)(cx + e.bl + r.tail.x + sc);
     }
     if constexpr (!(KIND == 0 && DIR == 0)) step(e);
   }
