@@ -1,5 +1,7 @@
+"""Gradient error of the log-domain fused tier alone (pipeline forced to fused5: the roles that redo what the linear-domain kernel
+flags) against the float64 C oracle, at the shapes DESIGN.md section 2 quotes.  GPU tool: python tests/tools/log_domain_tier_accuracy.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import c_oracle as C
 from tf_seq2seq_losses_amd import _lib, ops
