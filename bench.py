@@ -139,17 +139,24 @@ def _dist(us):
 
 def prewarm(fn, min_ms=100.0, max_calls=4000):
     """Runs fn() until at least min_ms of device time has passed on the current stream (clocks, caches and the HBM power state
-    in their steady state whatever --warmup says); returns the number of calls made."""
-    n, spent = 0, 0.0
-    while spent < min_ms and n < max_calls:
+    in their steady state whatever --warmup says) AND the launch time has settled -- the last three runs of 16 calls within 3 % of
+    the fastest run seen -- or 4 x min_ms have passed; returns the number of calls made.  (r04, rocprofv3 trace of the headline on
+    one box: 140 us per launch for the first 12 launches after an idle period, 160-183 us for the next 40, 139 us from then on --
+    a timed region of 20 steps that starts inside such an excursion reads 5 % high.)"""
+    n, spent, per = 0, 0.0, []
+    while n < max_calls:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(16):
             fn()
         b.record()
         b.synchronize()
-        spent += a.elapsed_time(b)
+        t = a.elapsed_time(b)
+        spent += t
+        per.append(t)
         n += 16
+        if spent >= min_ms and ((len(per) >= 3 and max(per[-3:]) <= 1.03 * min(per)) or spent >= 4 * min_ms):
+            break
     return n
 
 
@@ -255,6 +262,8 @@ def _sum_step_factory(lib, _lib, ops, device, rank, nbuf, B=256, T=1000, U=128, 
     loss = torch.empty(B, dtype=torch.float32, device=device)
     grad = torch.empty((B, T, V), dtype=torch.float32, device=device)
     sums = torch.zeros((nbuf, 2), dtype=torch.int64, device=device)
+    rows = [sums[k] for k in range(nbuf)]
+    ptrs = [r.data_ptr() for r in rows]
     x = dev["logits"]
     args = (0, _lib.WRT_LOGITS, x.data_ptr(), _lib.F32, x.stride(0), x.stride(1), prep.labels.data_ptr(), prep.stride,
             prep.label_length.data_ptr(), prep.logit_length.data_ptr(), 0, B, T, V, U, loss.data_ptr(), grad.data_ptr(),
@@ -264,10 +273,10 @@ def _sum_step_factory(lib, _lib, ops, device, rank, nbuf, B=256, T=1000, U=128, 
     def step():
         k = state["i"] % nbuf
         state["i"] += 1
-        rc = lib.ctc_amd_loss_grad_sum(*args, sums[k].data_ptr(), sums[(k + 1) % nbuf].data_ptr(), ws.data_ptr(), ws.numel(),
+        rc = lib.ctc_amd_loss_grad_sum(*args, ptrs[k], ptrs[(k + 1) % nbuf], ws.data_ptr(), ws.numel(),
                                        torch.cuda.current_stream().cuda_stream)
         assert rc == 0
-        return sums[k]
+        return rows[k]
 
     def reset():  # (a new loop starts at row 0 with every row clear)
         state["i"] = 0
@@ -569,6 +578,13 @@ def main():
         # (--reduce-every R: the pairs of R consecutive steps go out in one all-reduce -- R rows per group, depth + 2 groups)
         NBUF = (args.pipeline_depth + 2) * args.reduce_every
         sums = torch.zeros((NBUF, 2), dtype=torch.int64, device=device)
+        # row addresses and group views made HERE: the first tensor-indexing operation of a process costs ~150 us of dispatch set-up,
+        # and inside the timed region that was idle time between the first event and the first launch (first run of four launches
+        # read 172-183 us per launch instead of 137)
+        sum_rows = [sums[k] for k in range(NBUF)]
+        sum_ptr = [r.data_ptr() for r in sum_rows]
+        stream_h, ws_ptr, ws_n = torch.cuda.current_stream().cuda_stream, ws.data_ptr(), ws.numel()
+        group_views = [sums[g * args.reduce_every:(g + 1) * args.reduce_every] for g in range(args.pipeline_depth + 2)]
         native = args.dtype != "f32" or args.time_major
         if native:  # producer formats through ctc_amd_loss_grad_ex: no conversion pass anywhere
             xf = dev["logits"].to(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
@@ -588,11 +604,10 @@ def main():
 
             def step_sum(k):  # the same call + sum(loss) accumulated inside the launch (ctc_amd_loss_grad_sum)
                 a = ex_args
-                rc = lib.ctc_amd_loss_grad_sum(*a[:21], sums[k].data_ptr(), sums[(k + 1) % NBUF].data_ptr(), a[21], a[22],
-                                               torch.cuda.current_stream().cuda_stream)
+                rc = lib.ctc_amd_loss_grad_sum(*a[:21], sum_ptr[k], sum_ptr[(k + 1) % NBUF], a[21], a[22], stream_h)
                 if rc:
                     _lib.check(rc, "ctc_amd_loss_grad_sum")
-                return sums[k]
+                return sum_rows[k]
         else:
             args_c = prep.common(kind, _lib.WRT_LOGITS) + (loss.data_ptr(), grad.data_ptr(), None, ws.data_ptr(), ws.numel())
 
@@ -607,11 +622,10 @@ def main():
                         _lib.F32, grad.stride(0), grad.stride(1), None)
 
             def step_sum(k):  # the same call + sum(loss) accumulated inside the launch (ctc_amd_loss_grad_sum)
-                rc = lib.ctc_amd_loss_grad_sum(*sum_args, sums[k].data_ptr(), sums[(k + 1) % NBUF].data_ptr(), ws.data_ptr(), ws.numel(),
-                                               torch.cuda.current_stream().cuda_stream)
+                rc = lib.ctc_amd_loss_grad_sum(*sum_args, sum_ptr[k], sum_ptr[(k + 1) % NBUF], ws_ptr, ws_n, stream_h)
                 if rc:
                     _lib.check(rc, "ctc_amd_loss_grad_sum")
-                return sums[k]
+                return sum_rows[k]
         alg_bytes = B * 2 * T * V * (2 if args.dtype == "bf16" else 4)
 
     # The reduced scalars are read one step later (a training loop logs them), so the all-reduce of step i is issued
@@ -664,7 +678,8 @@ def main():
     grouped = in_kernel_sum and args.reduce_every > 1
     cdist.pipelined_steps(timed_step, args.steps, reduced=in_kernel_sum, depth=args.pipeline_depth, all_reduce=emu,
                           consume=(lambda i, pair: seen.append(pair.reshape(-1, 2)[-1]) if i == args.steps - 1 else None) if in_kernel_sum else None,
-                          **(dict(every=args.reduce_every, group_view=lambda first, n: sums[first % NBUF:first % NBUF + n]) if grouped else {}))
+                          **(dict(every=args.reduce_every, group_view=lambda first, n: (group_views[(first % NBUF) // args.reduce_every] if n == args.reduce_every
+                                                                                            else group_views[(first % NBUF) // args.reduce_every][:n])) if grouped else {}))
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -739,7 +754,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src if not args.hessian else None,
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_ms_per_launch": kernel_ms, "device_ms_per_step_incl_reduction": dev_ms_per_step,
-                         "kernel_us_in_timed_region": dict(_dist([t * 1e3 for t in kernel_ts]), what=f"per launch, event pairs around runs of {KEV} launches"),
+                         "kernel_us_in_timed_region": dict(_dist([t * 1e3 for t in kernel_ts]), in_order=[round(t * 1e3, 1) for t in kernel_ts],
+                                                           what=f"per launch, event pairs around runs of {KEV} launches"),
                          "kernel_us_after_timed_region": dict(_dist(post), what="100 more launches, an event pair around EACH (adds the event packets' own time)") if post else None},
             "warmup_effective": args.warmup + extra_warm,
             "box": box_probe(lib, device) if world == 1 else None,

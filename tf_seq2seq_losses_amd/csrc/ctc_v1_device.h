@@ -172,9 +172,13 @@ struct ScanCfg { static constexpr int PF = NL <= 2 ? 16 : (NL == 4 ? 8 : (NL == 
 // The steady-state loop is straight-line code (PF steps unrolled, no branches) so that hipcc emits counted
 // s_waitcnt vmcnt(N): each step waits only for the emission row issued PF steps earlier, never for the
 // prefetches and row stores still in flight.
+// The lattice state is float64 since r04 (rows stay float32: one rounding where a row is written, none accumulated along the sweep):
+// the float32 log-sum-exp chain was what this pipeline's gradient error consisted of -- 1.4e-4 / 1.9e-4 at T = 1000 with N(0, 4^2)
+// logits, 1.4e-4 at T = 3000 (tests/tools/logdomain_error_model.py; ctc_common.h lse2(double, double)).
 template <int KIND, int NL, int DIR>
 struct Scan {
-  float c[NL], o[NL], cx;
+  using ST = double;
+  ST c[NL], o[NL], cx;
   double off;
   bool norep[NL], norep_next[NL];
 
@@ -182,23 +186,23 @@ struct Scan {
     const float bl = e.bl;
     if constexpr (KIND == 0 && DIR == 0) {
       // alpha step (classic_ctc_loss.py:415-451)
-      float m[NL], x[NL];
+      ST m[NL], x[NL];
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
         m[j] = lse2(c[j], o[j]);
         x[j] = norep_next[j] ? m[j] : c[j];  // what position l+1 may continue from
       }
-      float xin0 = from_prev_lane(x[NL - 1], cx);
+      ST xin0 = from_prev_lane(x[NL - 1], cx);
 #pragma unroll
       for (int j = NL - 1; j >= 0; --j) {
-        float xin = (j == 0) ? xin0 : x[j - 1];
+        ST xin = (j == 0) ? xin0 : x[j - 1];
         o[j] = e.y[j] + lse2(o[j], xin);
         c[j] = bl + m[j];
       }
       cx += bl;
     } else if constexpr (KIND == 0 && DIR == 1) {
       // beta step (classic_ctc_loss.py:349-364)
-      float h[NL], ee[NL], pn[NL], x[NL];
+      ST h[NL], ee[NL], pn[NL], x[NL];
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
         h[j] = bl + c[j];
@@ -207,28 +211,28 @@ struct Scan {
         x[j] = norep[j] ? pn[j] : h[j];
       }
       cx += bl;
-      float xinl = from_next_lane(x[0], cx);
+      ST xinl = from_next_lane(x[0], cx);
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
-        float xin = (j == NL - 1) ? xinl : x[j + 1];
+        ST xin = (j == NL - 1) ? xinl : x[j + 1];
         o[j] = lse2(xin, ee[j]);
         c[j] = pn[j];
       }
     } else if constexpr (KIND == 1 && DIR == 0) {
       // simplified alpha step (simplified_ctc_loss.py:393-424)
-      float pin0 = from_prev_lane(c[NL - 1], cx);
+      ST pin0 = from_prev_lane(c[NL - 1], cx);
 #pragma unroll
       for (int j = NL - 1; j >= 0; --j) {
-        float pin = (j == 0) ? pin0 : c[j - 1];
+        ST pin = (j == 0) ? pin0 : c[j - 1];
         c[j] = lse2(bl + c[j], e.y[j] + pin);
       }
       cx += bl;
     } else {
       // simplified beta step (simplified_ctc_loss.py:327-343)
-      float nin = from_next_lane(c[0], cx);
+      ST nin = from_next_lane(c[0], cx);
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
-        float nx = (j == NL - 1) ? nin : c[j + 1];
+        ST nx = (j == NL - 1) ? nin : c[j + 1];
         c[j] = lse2(bl + c[j], e.y[j] + nx);
       }
       cx += bl;
@@ -237,11 +241,11 @@ struct Scan {
 
   // exact renormalisation: subtract the row maximum, remember it in `off` (branch-free)
   __device__ __forceinline__ void renorm() {
-    float mx = cx;
+    float mx = (float)cx;  // (any common shift will do: the float32 image of the maximum)
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      mx = fmaxf(mx, c[j]);
-      if constexpr (KIND == 0) mx = fmaxf(mx, o[j]);
+      mx = fmaxf(mx, (float)c[j]);
+      if constexpr (KIND == 0) mx = fmaxf(mx, (float)o[j]);
     }
     mx = wave_max(mx);
     mx = (mx > NEG_THR) ? mx : 0.f;
@@ -261,22 +265,26 @@ struct Scan {
   __device__ __forceinline__ void store_row(float *__restrict__ row, int lane, int UP) const {
     const float oh = (float)off;
     const float ol = (float)(off - (double)oh);
+    float cf[NL], of[NL];  // (rows are float32)
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { cf[j] = (float)c[j]; of[j] = (float)o[j]; }
+    const float cxf = (float)cx;
     if constexpr (DIR == 0) {
       if constexpr (KIND == 0) {
-        store_pairs<NL>(row, lane, c, o);
-        if (!ONE || lane == 0) *reinterpret_cast<float4 *>(row + 2 * UP) = make_float4(cx, NEG, oh, ol);
+        store_pairs<NL>(row, lane, cf, of);
+        if (!ONE || lane == 0) *reinterpret_cast<float4 *>(row + 2 * UP) = make_float4(cxf, NEG, oh, ol);
       } else {
-        store_singles<NL>(row, lane, c);
-        if (!ONE || lane == 0) *reinterpret_cast<float4 *>(row + UP) = make_float4(cx, 0.f, oh, ol);
+        store_singles<NL>(row, lane, cf);
+        if (!ONE || lane == 0) *reinterpret_cast<float4 *>(row + UP) = make_float4(cxf, 0.f, oh, ol);
       }
     } else {
       float cs[NL];  // state of label position l = i+1 lives in the next slot's c
 #pragma unroll
-      for (int j = 0; j < NL - 1; ++j) cs[j] = c[j + 1];
-      cs[NL - 1] = from_next_lane(c[0], cx);
-      const float c00 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c[0])));  // state l = 0 (lane 0, slot 0)
+      for (int j = 0; j < NL - 1; ++j) cs[j] = cf[j + 1];
+      cs[NL - 1] = from_next_lane(cf[0], cxf);
+      const float c00 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cf[0])));  // state l = 0 (lane 0, slot 0)
       if constexpr (KIND == 0) {
-        store_pairs<NL>(row, lane, cs, o);
+        store_pairs<NL>(row, lane, cs, of);
         if (!ONE || lane == 0) *reinterpret_cast<float4 *>(row + 2 * UP) = make_float4(c00, c00, oh, ol);
       } else {
         store_singles<NL>(row, lane, cs);
@@ -372,9 +380,9 @@ __device__ __forceinline__ void scan_body(const Problem &p, const Layout &L, con
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       int i = lane * NL + j;
-      if (i == ll - 1) mine = (KIND == 0) ? lse2(S.c[j], S.o[j]) : S.c[j];
+      if (i == ll - 1) mine = (float)((KIND == 0) ? lse2(S.c[j], S.o[j]) : S.c[j]);
     }
-    float v = (ll == 0) ? S.cx : wave_max(mine);
+    float v = (ll == 0) ? (float)S.cx : wave_max(mine);
     if (lane == 0) {
       if (v > NEG_THR) {
         double lp2 = (double)v + S.off;
