@@ -649,7 +649,7 @@ __device__ __forceinline__ void run_main(const Problem &p, float *__restrict__ r
         const int g = geo.absblock(1, DIR, j);
         const int nv = geo.nvof(g);
         const float(*E)[C::ES] = lds.E[DIR][j % 3];
-        spill(geo.slot(DIR == 0 ? BLK * g : BLK * g + nv));
+        if (!(lds.mode & 8)) spill(geo.slot(DIR == 0 ? BLK * g : BLK * g + nv));
         if (nv == BLK) {
           // the emission rows of the whole block go to registers first: the sequential chain never waits for an LDS round trip
           Emis<NL> eb[BLK];
