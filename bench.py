@@ -692,6 +692,17 @@ def main():
         want = float(loss[fin].double().sum())
         got, cnt = float(seen[0][0]) / 1048576.0, int(seen[0][1])
         assert cnt == int(fin.sum()) and abs(got - want) <= 1e-6 * max(1.0, abs(want)) + B * 1e-6, (got, want, cnt)
+    reduced_check = None
+    if in_kernel_sum and world > 1 and seen:
+        # (outside the timed region) the pair of the last step as the collective left it on this rank against an independent
+        # reduction of the ranks' own losses: the same count, the same sum in fixed point -- on every rank
+        fin = torch.isfinite(loss)
+        own = torch.stack([torch.round(loss[fin].double() * 1048576.0).sum().to(torch.int64), fin.sum().to(torch.int64)])
+        dist.all_reduce(own, op=dist.ReduceOp.SUM)
+        got = seen[0].to(torch.int64)
+        assert int(got[1]) == int(own[1]) and abs(int(got[0]) - int(own[0])) <= 2 * B * world, (got.tolist(), own.tolist())
+        reduced_check = dict(finite_utterances_all_ranks=int(got[1]), sum_loss_all_ranks=float(got[0]) / 1048576.0,
+                             what="the all-reduced [sum(loss), count] pair of the last timed step, equal to an independent reduction of the ranks' losses")
     tmax = torch.tensor([wall], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -759,6 +770,7 @@ def main():
                          "kernel_us_after_timed_region": dict(_dist(post), what="100 more launches, an event pair around EACH (adds the event packets' own time)") if post else None},
             "warmup_effective": args.warmup + extra_warm,
             "box": box_probe(lib, device) if world == 1 else None,
+            "reduced_check": reduced_check,
         }
         if not args.no_cpu_baseline and not args.hessian and world == 1:  # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(args.kind, host)
