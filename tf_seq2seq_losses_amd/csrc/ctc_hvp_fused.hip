@@ -41,7 +41,10 @@ namespace hvpf {
 
 using namespace ctc::fused;
 
-constexpr int BLK = HVPF_BLK, NH = 3, RN = 3, NG = BLK / RN, NW = 4 + 2 * NH;  // 10 wavefronts: 4 chains + 3 helpers a side
+#ifndef CTC_HVPF_RN
+#define CTC_HVPF_RN 3   // frames between renormalisations of a chain (experiment builds: scripts/build_hvp_variant.sh -DCTC_HVPF_RN=6)
+#endif
+constexpr int BLK = HVPF_BLK, NH = 3, RN = CTC_HVPF_RN, NG = BLK / RN, NW = 4 + 2 * NH;  // 10 wavefronts: 4 chains + 3 helpers a side
 constexpr int V = 256;
 using linear::DEAD; using linear::GAP; using linear::GAP_WIDE; using linear::DOWN_MAX; using linear::DECAY_MAX; using linear::KK_MAX;
 using linear::EMIS_MIN; using linear::MASS_TOL;  // (ctc_linear_flags.h: one copy for this kernel and ctc_fused6.hip)
