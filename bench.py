@@ -643,6 +643,12 @@ def main():
     # ... and, whatever --warmup says, at least 100 ms of the timed launch: a cold process ran its first ~25 launches 10 %
     # slow (r02: driver 174 us at --warmup 5 against 152-157 us at --warmup 20 on the same commit)
     extra_warm = prewarm(step, args.prewarm_ms) if args.prewarm_ms > 0 else 0
+    if world > 1 and not args.hessian:
+        # the collective of the timed region once before it, on the (still all-zero) rows it will carry: RCCL sets up a datatype /
+        # message-size combination on first use, and the warm-up steps above reduce a float32 pair, not int64[R, 2]
+        import torch.distributed as dist
+        for gv in group_views:
+            dist.all_reduce(gv, op=dist.ReduceOp.SUM)
     emu = EmulatedAllReduce(lib, device) if (args.emulate_collective and world == 1) else None
     if emu is not None:  # (its stream, events and kernel exist before the timed region)
         for _ in range(8):
