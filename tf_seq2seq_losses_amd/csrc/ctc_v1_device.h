@@ -357,6 +357,10 @@ __device__ __forceinline__ void scan_body(const Problem &p, const Layout &L, con
 #pragma unroll
       for (int d = 0; d < PF; ++d) {
         S.step(buf[d]);
+        // (the refill stays BEHIND the step that uses the slot: hoisted above it by the scheduler, old and new row were alive together,
+        // the slot changed registers every trip and the copies at the loop's edge waited for every load of the trip -- s_waitcnt
+        // vmcnt(0) at the head of each unrolled block, r04, after the float64 state had changed the register allocation)
+        __builtin_amdgcn_sched_barrier(0);
         load_erow<NL>(buf[d], erow_ptr(k0 + d + PF), lane, UP, vz);  // clamped: re-reads the last row near the end
         if (d == RENORM - 1) S.renorm();
 #ifndef CTC_EXPERIMENT_NO_STORE
