@@ -15,11 +15,11 @@ python3 - <<'PY'
 import csv, glob, statistics as st
 f = glob.glob("gpurun_out/r04_final/trace/*/*_kernel_trace.csv")
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f[0])) if "fused6" in r["Kernel_Name"]]
-t = sorted(d[-220:])
+t = sorted(d[-300:-100])  # (order of launches: warm-up steps, pre-warm, the 200 timed steps, 100 more with an event pair around each)
 open("gpurun_out/r04_final/fused6_durations.txt", "w").write(
     "rocprofv3 --kernel-trace of `python3 bench.py --steps 200 --warmup 20`: fused6_kernel<0, 2, 4, 12, 1, 0>\n"
-    f"all {len(d)} launches (incl. the 150 ms pre-warm): first 40 (us): {[round(x) for x in d[:40]]}\n"
-    f"last 220 launches (20 warm-up + 200 timed): min {t[0]:.1f} median {st.median(t):.1f} mean {st.mean(t):.1f} p90 {t[int(len(t) * .9)]:.1f} max {t[-1]:.1f} us\n")
+    f"all {len(d)} launches (incl. the pre-warm): first 40 (us): {[round(x) for x in d[:40]]}\n"
+    f"the 200 timed launches: min {t[0]:.1f} median {st.median(t):.1f} mean {st.mean(t):.1f} p90 {t[int(len(t) * .9)]:.1f} max {t[-1]:.1f} us\n")
 print(open("gpurun_out/r04_final/fused6_durations.txt").read())
 PY
 cp $OUT/trace/*/*_kernel_stats.csv $OUT/fused6_kernel_stats.csv

@@ -69,7 +69,7 @@ __device__ __forceinline__ float lse2(float a, float b) {
 }
 
 // The same on a float64 state (the log-domain roles of the fused tiers since r04: the sweep's log-sum-exp chain is what carries
-// their error -- host-side model scratch-free in DESIGN.md section 2: float32 chain 2e-5 ... 8e-5 of posterior error at T = 1000
+// their error -- tests/tools/logdomain_error_model.py, DESIGN.md section 2: float32 chain 2e-5 ... 8e-5 of posterior error at T = 1000
 // with N(0, 4^2) logits, float64 chain 9e-7 with the SAME float32 emissions; the transcendental part stays float32: its argument
 // is a difference, its result lies in [0, 1]).  gfx950 issues v_add_f64 / v_max_f64 at the float32 rate.
 __device__ __forceinline__ double lse2(double a, double b) {
