@@ -565,7 +565,7 @@ int ctc_amd_hvp(int kind, int wrt, const float *logits, const int32_t *labels, i
     if (ef != hipSuccess) return hip_fail(ef, "fused hvp launch");
     return CTC_AMD_OK;
   }
-  hipError_t e = ctc::run_emit_scan(p, L, ws, loss, 2, st);
+  hipError_t e = ctc::run_emit_scan(p, L, ws, loss, 2 | 4, st);  // (+ 4: rows renormalised every step, for the tangent sweep)
   if (e != hipSuccess) return hip_fail(e, "emit/scan launch");
   if (grad) {
     e = ctc::run_grad(p, L, ws, nullptr, grad, st);

@@ -1143,8 +1143,8 @@ __device__ __forceinline__ void redo_log_domain(const Problem &p, const Layout &
   // same CU through the shared L1, as at the meeting point of the chains)
   for (int t = w; t < p.T; t += NW) emit_row(p, L, emis, b, t, lane);
   __syncthreads();
-  if (w == 0) scan_body<KIND, NL, 0>(p, L, emis, alpha, logp, loss, b, lane);
-  else if (w == 1) scan_body<KIND, NL, 1>(p, L, emis, beta, logp, loss, b, lane);
+  if (w == 0) scan_body<KIND, NL, 0, true>(p, L, emis, alpha, logp, loss, b, lane);   // (rows renormalised every step: the tangent sweep reads them)
+  else if (w == 1) scan_body<KIND, NL, 1, true>(p, L, emis, beta, logp, loss, b, lane);
   else for (int t = w - 2; t < p.T; t += NW - 2) temit_row(p, L, emis, vec, demis, b, t, lane);  // (beside the value sweeps)
   __syncthreads();
   if (w < 2) tscan_body<KIND, NL>(p, L, emis, demis, alpha, beta, logp, dalpha, dbeta, dlogp, b, w, lane);

@@ -460,18 +460,20 @@ namespace ctc {
 
 // grid (B, ndir): blockIdx.y = 0 runs the alpha sweep, 1 the beta sweep.  The two sweeps are independent
 // (beta never reads alpha), so one launch puts both wavefronts of an utterance on the chip at once.
-template <int KIND, int NL>
+template <int KIND, int NL, bool FINE>
 __global__ __launch_bounds__(64) void scan_kernel(Problem p, Layout L, const float *__restrict__ emis,
                                                    float *__restrict__ alpha, float *__restrict__ beta,
                                                    double *__restrict__ logp, float *__restrict__ loss) {
-  if (blockIdx.y == 0) scan_body<KIND, NL, 0>(p, L, emis, alpha, logp, loss, blockIdx.x, threadIdx.x);
-  else scan_body<KIND, NL, 1>(p, L, emis, beta, logp, loss, blockIdx.x, threadIdx.x);
+  if (blockIdx.y == 0) scan_body<KIND, NL, 0, FINE>(p, L, emis, alpha, logp, loss, blockIdx.x, threadIdx.x);
+  else scan_body<KIND, NL, 1, FINE>(p, L, emis, beta, logp, loss, blockIdx.x, threadIdx.x);
 }
 
+// ndir: 1 = alpha only, 2 = both sweeps; + 4 = rows renormalised every step (scan_body FINE: the Hessian-vector product's pipeline)
 template <int KIND, int NL>
 static void launch_scan_nl(const Problem &p, const Layout &L, const float *emis, float *alpha, float *beta, double *logp,
                            float *loss, int ndir, hipStream_t st) {
-  hipLaunchKernelGGL((scan_kernel<KIND, NL>), dim3(p.B, ndir), dim3(64), 0, st, p, L, emis, alpha, beta, logp, loss);
+  if (ndir & 4) hipLaunchKernelGGL((scan_kernel<KIND, NL, true>), dim3(p.B, ndir & 3), dim3(64), 0, st, p, L, emis, alpha, beta, logp, loss);
+  else hipLaunchKernelGGL((scan_kernel<KIND, NL, false>), dim3(p.B, ndir & 3), dim3(64), 0, st, p, L, emis, alpha, beta, logp, loss);
 }
 
 template <int KIND>

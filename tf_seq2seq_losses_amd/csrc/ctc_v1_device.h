@@ -180,6 +180,7 @@ struct Scan {
   using ST = double;
   ST c[NL], o[NL], cx;
   double off;
+  float mpend = 0.f;  // renorm_lagged: the row maximum measured one step ago, not yet subtracted
   bool norep[NL], norep_next[NL];
 
   __device__ __forceinline__ void step(const ERow<NL> &e) {
@@ -256,6 +257,32 @@ struct Scan {
     }
     cx -= mx;
     off += (double)mx;
+    mpend = 0.f;
+  }
+
+  // Per-step renormalisation off the critical path: subtracts the row maximum measured ONE STEP AGO (its wave reduction ran beside
+  // this step's log-sum-exps; a state rises by at most log2(3) per step) and measures the present one for the next step.  The state
+  // itself does not need it (float64) -- the ROWS do: they are stored in float32, and a row written 15 steps after the last exact
+  // renormalisation carries magnitudes of hundreds on sharp logits, i.e. a rounding of 3e-5 per entry, which the tangent sweep of
+  // the Hessian-vector product (weights 2^(argument - result) from consecutive rows) accumulates (r04: one redone utterance of
+  // ~8 000 at 1.13e-4 of max|Hv|, tests/tools/soak_hvp.py seed 21).
+  __device__ __forceinline__ void renorm_lagged() {
+    const float m = mpend;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      c[j] -= m;
+      if constexpr (KIND == 0) o[j] -= m;
+    }
+    cx -= m;
+    off += (double)m;
+    float mx = (float)cx;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      mx = fmaxf(mx, (float)c[j]);
+      if constexpr (KIND == 0) mx = fmaxf(mx, (float)o[j]);
+    }
+    mx = wave_max(mx);
+    mpend = (mx > NEG_THR) ? mx : 0.f;
   }
 
   // row layout: see Layout in ctc_common.h.  The 16-byte tail (l = 0 state + offset) is wave-uniform data
@@ -294,7 +321,9 @@ struct Scan {
   }
 };
 
-template <int KIND, int NL, int DIR>
+// FINE: the rows are renormalised every step (Scan::renorm_lagged) -- for the tangent sweep of the Hessian-vector product, which
+// reads consecutive rows against each other; costs the scan ~10 % and is off for the loss / gradient pipeline.
+template <int KIND, int NL, int DIR, bool FINE = false>
 __device__ __forceinline__ void scan_body(const Problem &p, const Layout &L, const float *__restrict__ emis,
                                           float *__restrict__ rows_all, double *__restrict__ logp,
                                           float *__restrict__ loss, int b, int lane) {
@@ -363,6 +392,7 @@ __device__ __forceinline__ void scan_body(const Problem &p, const Layout &L, con
         __builtin_amdgcn_sched_barrier(0);
         load_erow<NL>(buf[d], erow_ptr(k0 + d + PF), lane, UP, vz);  // clamped: re-reads the last row near the end
         if (d == RENORM - 1) S.renorm();
+        else if constexpr (FINE) S.renorm_lagged();
 #ifndef CTC_EXPERIMENT_NO_STORE
         S.store_row(out_row(k0 + d), lane, UP);
 #endif
@@ -373,6 +403,7 @@ __device__ __forceinline__ void scan_body(const Problem &p, const Layout &L, con
     for (int d = 0; d < PF; ++d) {
       if (k0 + d < len) {
         S.step(buf[d]);
+        if constexpr (FINE) S.renorm_lagged();
         S.store_row(out_row(k0 + d), lane, UP);
       }
     }
