@@ -551,7 +551,10 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL> &S, Lds<KIND, NL> &
   // rows are loaded PFD blocks ahead of their use, in a ring of register sets addressed by (block mod PFD) at COMPILE time (the
   // loop is unrolled by PFD): a 6-frame block lasts ~0.7 us, an HBM load under load ~2 us -- with one block of look-ahead every
   // iteration waited for memory (phase 1: 165 us instead of ~70)
-  constexpr int PFD = 4;
+#ifndef CTC_HVPF_PFD
+#define CTC_HVPF_PFD 4
+#endif
+  constexpr int PFD = CTC_HVPF_PFD;
   float4 xb[PFD][NQ], vb[PFD][NQ];
   static_for<0, PFD>([&](auto R) {
     constexpr int r = decltype(R)::value;
@@ -609,7 +612,7 @@ __device__ __forceinline__ void estage1(const Rows<KIND, NL> &S, Lds<KIND, NL> &
     for (int q = 0; q < NQ; ++q) S.load_xv(xb[r][q], vb[r][q], fr(j + PFD, P0 + q));
     block_barrier_raw();
   };
-  static_assert(PFD == 4, "Geo::NI1 is rounded to this ring depth");
+  static_assert(4 % PFD == 0, "Geo::NI1 is rounded to a multiple of four iterations");
   for (int it0 = 0; it0 < geo.NI1; it0 += PFD) {
     static_for<0, PFD>([&](auto R) { body(R, it0 + decltype(R)::value); });
   }
