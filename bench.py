@@ -663,7 +663,10 @@ def main():
     # each around a run of KEV consecutive launches (a pair around every single launch adds the 5-8 us the stream needs to
     # process the two event packets to the kernel it brackets and serialises its dispatch behind them: 158 against 150 us
     # here) -- launch duration = bracketed time / KEV, averaged over the K steps; the number the roofline fraction is priced on
-    KEV = 4
+    # (8 launches per pair since the end of r04: the two event packets between two runs cost the stream ~10 us of idle time -- the
+    # rocprofv3 trace shows it as a 10 us gap before every run -- which is outside the brackets but inside the wall clock `value`
+    # comes from: 2.5 us per step with runs of four, 1.25 with runs of eight)
+    KEV = 8
     ngrp = (args.steps + KEV - 1) // KEV
     kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(ngrp)]
     in_kernel_sum = not args.hessian
